@@ -1,0 +1,109 @@
+"""G3 / G4: the oracle's tree search and self-play loop against the reference's MCT and
+AlphaZeroTrainer.self_play under the closed-form fake net and deterministic tie-breaks.
+Visit counts exact, Q within 1e-12, priors within 1e-12 (dyadic fake priors make them exact)."""
+import numpy as np
+import pytest
+
+from conftest import TAGS, golden
+from oracle import oracle as O
+
+MCT_TAGS = ["othello8", "othello6", "connect4", "tictactoe"]
+
+
+def run_case(gid, H, W, grid, player, noise):
+    b = O.new_board(gid, H, W)
+    b.set_grid(grid, player)
+    t = O.MCT(("fake", None), alpha=0.03 if noise else -1.0, eps=0.25 if noise else -1.0, tie_mode=O.TIE_LOWEST,
+              noise_mode=O.NOISE_HASH if noise else O.NOISE_OFF)
+    out = []
+    for s in (1, 1, 8, 90):
+        t.search(b, s)
+        out.append((t.root_children(), t.root_n(), -1))
+    act, pi, vis = t.choose(b, 0.0)
+    assert O.lib().orc_play(O.C.byref(b), act) == 0
+    t.change_root(act)
+    if not O.lib().orc_is_over(O.C.byref(b)):
+        t.search(b, 100)
+        out.append((t.root_children(), t.root_n(), act))
+    return out
+
+
+@pytest.mark.parametrize("tag", MCT_TAGS)
+def test_mct_fixture(tag):
+    game, gid, H, W, A, n = TAGS[tag]
+    fx = golden(f"mct_{tag}.npz")
+    ro = fx["row_off"]
+    rec = 0
+    n_rec = len(fx["stage"])
+    checked = 0
+    while rec < n_rec:
+        assert fx["stage"][rec] == 0
+        grid, player, noise = fx["grids"][rec], int(fx["players"][rec]), int(fx["noise"][rec])
+        res = run_case(gid, H, W, grid, player, noise)
+        k = 0
+        while rec < n_rec and (k == 0 or fx["stage"][rec] != 0):
+            (a, N, Q, P), rootn, moved = res[k]
+            sl = slice(ro[rec], ro[rec + 1])
+            assert np.array_equal(a, fx["action"][sl]), (tag, rec)
+            assert np.array_equal(N, fx["N"][sl]), (tag, rec)
+            assert rootn == fx["rootN"][rec]
+            assert moved == fx["moved"][rec]
+            assert np.abs(Q - fx["Q"][sl]).max() <= 1e-12
+            assert np.abs(P - fx["P"][sl]).max() <= 1e-12
+            rec += 1
+            k += 1
+            checked += 1
+        assert k == len(res)
+    assert checked == n_rec and checked > 100
+
+
+@pytest.mark.parametrize("tag", MCT_TAGS)
+def test_selfplay_fixture(tag):
+    """AlphaZeroTrainer.self_play (trainer.py:215-273) sample stream, un-augmented part."""
+    game, gid, H, W, A, n = TAGS[tag]
+    fx = golden(f"selfplay_{tag}.npz")
+    names = [str(x) for x in fx["transf_names"]]
+    orig = fx["transformation"] == names.index("None")
+    r = O.selfplay(gid, H, W, int(fx["episodes"]), int(fx["sims"]), ("fake", None), alpha=float(fx["alpha"]),
+                   eps=float(fx["eps"]), temp_max_step=int(fx["temp_max_step"]), temp_min_step=int(fx["temp_min_step"]),
+                   tie_mode=O.TIE_LOWEST, noise_mode=O.NOISE_HASH, seed=int(fx["seed"]))
+    S = int(orig.sum())
+    assert len(r["z"]) == S
+    assert np.array_equal(r["state"], fx["state"][orig])
+    assert np.array_equal(r["z"], fx["outcome"][orig])
+    assert np.array_equal(r["meta"][:, 0], fx["episode_idx"][orig])
+    assert np.array_equal(r["meta"][:, 1], fx["move_idx"][orig])
+    assert np.all(fx["player"] == 1)
+    assert np.abs(r["pi"].astype(np.float64) - fx["pi"][orig]).max() < 1e-7  # pi is stored as float32
+
+
+def test_tree_invariants_random_mode():
+    """N(root) = sum N(children) on a fresh root; production (random) mode runs."""
+    b = O.new_board(O.OTHELLO, 8, 8)
+    t = O.MCT(("fake", None), alpha=0.03, eps=0.25, tie_mode=O.TIE_RANDOM, noise_mode=O.NOISE_PHILOX, seed=3)
+    t.search(b, 100)
+    a, N, Q, P = t.root_children()
+    assert t.root_n() == 100 == N.sum()
+    assert abs(P.sum() - 1.0) < 1e-6
+    r1 = O.selfplay(O.OTHELLO, 8, 8, 2, 20, seed=5)
+    r2 = O.selfplay(O.OTHELLO, 8, 8, 2, 20, seed=5)
+    r3 = O.selfplay(O.OTHELLO, 8, 8, 2, 20, seed=6)
+    assert np.array_equal(r1["pi"], r2["pi"]) and np.array_equal(r1["state"], r2["state"])
+    assert not np.array_equal(r1["meta"][:, 3][:len(r3["meta"])], r3["meta"][:, 3][:len(r1["meta"])])
+
+
+def test_rollout_tictactoe_stats():
+    """BASELINE config 1 (TicTacToe, rollout MCTS, 100 sims, temp 0): outcome mix near the reference's."""
+    fx = golden("stats.npz")
+    n = 400
+    r = O.selfplay(O.TICTACTOE, 3, 3, n, 100, alpha=-1, eps=-1, temp_max_step=-1, temp_min_step=0,
+                   tie_mode=O.TIE_RANDOM, noise_mode=O.NOISE_OFF, seed=11, eval_method=O.EVAL_ROLLOUT)
+    last = np.flatnonzero(np.r_[r["meta"][1:, 1] == 0, True])
+    first = np.flatnonzero(r["meta"][:, 1] == 0)
+    assert len(first) == n
+    winner = r["z"][first] * r["meta"][first, 2]  # z is normalised by the player to move
+    draw = np.mean(winner == 0)
+    ref_draw = int(fx["ttt_rollout_draw"]) / int(fx["ttt_rollout_games"])
+    assert abs(draw - ref_draw) < 0.12, (draw, ref_draw)
+    plies = (last - first + 1).mean()
+    assert abs(plies - float(fx["ttt_rollout_mean_plies"])) < 0.5

@@ -1,0 +1,75 @@
+"""G2: the oracle's network forward (BN folded, fmaf chains in the HIP kernels' accumulation order)
+against the reference's torch forward under closed-form weights.  Tolerance 1e-5 abs."""
+import ast
+
+import numpy as np
+import pytest
+
+from conftest import TAGS, golden
+from oracle import oracle as O
+from tools import closed_form as cf
+
+TOL = 1e-5
+
+
+def oracle_net(tag, fx):
+    game, gid, H, W, A, n = TAGS[tag]
+    shapes = {str(k): ast.literal_eval(str(v)) for k, v in zip(fx["shape_keys"], fx["shape_vals"])}
+    sd = cf.closed_form_state_dict(shapes)
+    sd = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    return O.MlpNet(sd) if game == "tictactoe" else O.ConvNet(gid, H, W, sd)
+
+
+@pytest.mark.parametrize("tag", ["othello8", "othello6", "connect4", "tictactoe"])
+def test_known_answers(tag):
+    game, gid, H, W, A, n = TAGS[tag]
+    fx = golden(f"net_{tag}.npz")
+    net = oracle_net(tag, fx)
+    canon = fx["grids"].astype(np.float32) * fx["players"].astype(np.float32)[:, None, None]
+    probs, v = net.forward(canon)
+    assert np.abs(probs - fx["probs"]).max() < TOL
+    assert np.abs(v - fx["v"]).max() < TOL
+    assert np.abs(probs.sum(1) - 1).max() < 1e-5
+    # evaluate(): value is flipped back to the absolute frame by board.player (base.py:366)
+    k = len(fx["eval_v"])
+    assert np.abs(probs[:k] - fx["eval_probs"]).max() < TOL
+    assert np.abs(v[:k].astype(np.float64) * fx["players"][:k] - fx["eval_v"]).max() < TOL
+
+
+def test_param_counts():
+    # report p.7 Table 2 / SURVEY 6.1
+    assert int(golden("net_othello8.npz")["n_params"]) == 1115362
+    assert int(golden("net_othello6.npz")["n_params"]) == 707782
+    assert int(golden("net_connect4.npz")["n_params"]) == 43208
+    assert int(golden("net_tictactoe.npz")["n_params"]) == 316
+
+
+def test_det_math():
+    L = O.lib()
+    xs = np.linspace(-80, 0, 4001).astype(np.float32)
+    got = np.array([L.orc_det_expf(float(x)) for x in xs])
+    ref = np.exp(xs.astype(np.float64))
+    assert np.max(np.abs(got - ref) / ref) < 4e-7
+    xs = np.linspace(-6, 6, 2001).astype(np.float32)
+    got = np.array([L.orc_det_tanhf(float(x)) for x in xs])
+    assert np.max(np.abs(got - np.tanh(xs.astype(np.float64)))) < 3e-7
+    xs = np.exp(np.linspace(-40, 40, 3001))
+    got = np.array([L.orc_det_log(float(x)) for x in xs])
+    assert np.max(np.abs(got - np.log(xs))) < 1e-14 * 45
+    xs = np.linspace(-600, 5, 3001)
+    got = np.array([L.orc_det_exp(float(x)) for x in xs])
+    assert np.max(np.abs(got - np.exp(xs)) / np.exp(xs)) < 1e-14
+
+
+def test_philox_known_answer():
+    # Random123 known-answer vectors for philox4x32-10
+    import ctypes as C
+    L = O.lib()
+    out = (C.c_uint32 * 4)()
+    L.orc_philox4x32(0, 0, 0, 0, 0, 0, out)
+    assert list(out) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    L.orc_philox4x32(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, out)
+    assert list(out) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    L.orc_philox4x32(0xa4093822, 0x299f31d0, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, out)
+    assert list(out) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert cf.philox4x32(0xa4093822, 0x299f31d0, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344) == tuple(out)
