@@ -1,0 +1,14 @@
+// az_common.hip -- error reporting shared by every entry point of libaz_amd.so
+#include "az_host.h"
+
+static thread_local char g_err[512] = "";
+
+void az_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *az_last_error(void) { return g_err; }
+extern "C" int az_version(void) { return 100; }

@@ -1,0 +1,602 @@
+// az_net.hip -- policy-value network forward on MI355X (gfx950), float32 in / float32 accumulate.
+//
+// Replaces OthelloNet / Connect4Net / TicTacToeNet .forward in eval mode (othello.py:341-382,
+// connect4.py:370-412, tictactoe.py:289-316) + PolicyValueNetwork.predict (base.py:350-355).
+//
+// All matrix work runs on the f32-input matrix cores (v_mfma_f32_16x16x4_f32): exact f32
+// products and a k-ordered f32 accumulation chain, i.e. the reference's arithmetic type (the
+// reference computes in torch float32), not a reduced-precision path.  Eval-mode BatchNorm is
+// folded into the preceding layer in float64 at upload (az_net_commit).
+//
+// Accumulation order (restated by the CPU oracle so tests can demand bit equality):
+//   conv : acc = b'[oc]; for tap = ky*3+kx ascending, for ic ascending: acc = fma(in, w', acc); relu
+//   dense: acc = b'[n];  for k ascending: acc = fma(x[k], W'[n][k], acc); (relu)
+//   heads: softmax as m = max, e = det_exp(l - m), S = sequential sum, p = e / S; v = det_tanh
+//
+// Kernels
+//   k_trunk<CH,CW> : conv1 (VALU) + conv2..4 (implicit GEMM on MFMA), one wavefront per board,
+//                    activations never leave the wave's private LDS region; weights stream from
+//                    L2 already tiled in MFMA B-fragment order (one coalesced dword per lane).
+//   k_gemm<...>    : LDS-tiled f32 MFMA GEMM with bias(+ReLU) epilogue for fc1 / fc2.
+//   k_heads        : policy+value GEMM (N padded to 16) fused with softmax / tanh.
+//   k_mlp          : the 316-parameter TicTacToe MLP, one thread per board.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "az_device.h"
+#include "az_host.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define NCH 32
+// LDS plane stride: smallest value >= x that is 1 (mod 32) -> the 16 output channels a wave
+// instruction writes land on 16 distinct banks
+#define PLANE_STRIDE(x) ((((x) + 30) / 32) * 32 + 1)
+
+struct TrunkParams {
+    const float *w1, *b1;        // conv1 [9][32], [32]
+    const float *wf[3], *cb[3];  // conv2..4 B-fragment order [9][8][2][64], bias [32]
+};
+
+// implicit-GEMM 3x3 convolution of one board on MFMA.
+//   in_lds : [32 ic][IN_PS] planes of width IN_W; output position p=(y,x) of a W_OUT-wide plane reads
+//            in[(y+ky)*IN_W + (x+kx)]  (a halo, if any, is part of the input plane)
+//   M = P_OUT positions (MT tiles of 16), N = 32 oc (2 tiles), K = 9 taps x 32 ic
+template <int P_OUT, int W_OUT, int IN_W, int IN_PS, int MT>
+AZ_D void conv_mfma(const float *in_lds, const float *__restrict__ wf, const float *__restrict__ bias, int lane,
+                    f32x4 (&acc)[MT][2]) {
+    const int m_lane = lane & 15, kq = lane >> 4;
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int p = 16 * mt + m_lane;
+        p = p < P_OUT ? p : P_OUT - 1;
+        abase[mt] = kq * IN_PS + (p / W_OUT) * IN_W + (p % W_OUT);
+    }
+    const float bv0 = bias[m_lane], bv1 = bias[16 + m_lane];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][0] = (f32x4){bv0, bv0, bv0, bv0};
+        acc[mt][1] = (f32x4){bv1, bv1, bv1, bv1};
+    }
+    const float *wl = wf + lane;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int toff = (tap / 3) * IN_W + (tap % 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float b0 = wl[((tap * 8 + j) * 2 + 0) * 64];
+            const float b1 = wl[((tap * 8 + j) * 2 + 1) * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float a = in_lds[abase[mt] + toff + 4 * j * IN_PS];
+                acc[mt][0] = MFMA(a, b0, acc[mt][0]);
+                acc[mt][1] = MFMA(a, b1, acc[mt][1]);
+            }
+        }
+    }
+}
+
+template <int P_OUT, int OUT_PS, int MT>
+AZ_D void store_relu_lds(float *out, int lane, const f32x4 (&acc)[MT][2]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int m = 16 * mt + (lane >> 4) * 4 + r;
+                float v = acc[mt][nt][r];
+                if (m < P_OUT) out[(nt * 16 + (lane & 15)) * OUT_PS + m] = v > 0.0f ? v : 0.0f;
+            }
+}
+
+#define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int CH, int CW>
+struct TrunkGeom {
+    static constexpr int P1 = CH * CW, PW = CW + 2, PH = CH + 2;
+    static constexpr int PS1 = PLANE_STRIDE(PH * PW), PS2 = PLANE_STRIDE(P1);
+    static constexpr int H3 = CH - 2, W3 = CW - 2, P3 = H3 * W3, PS3 = PLANE_STRIDE(P3);
+    static constexpr int H4 = CH - 4, W4 = CW - 4, P4 = H4 * W4;
+    static constexpr int MT2 = (P1 + 15) / 16, MT3 = (P3 + 15) / 16, MT4 = (P4 + 15) / 16;
+    static constexpr int WAVE_FLOATS = NCH * (PS1 + PS2);
+    static constexpr int LDS_BYTES = 4 * WAVE_FLOATS * 4;
+    static_assert(PS3 <= PS1, "conv3 output reuses the conv1 region");
+    static_assert(PH * PW <= NCH * PS2, "input staging uses the conv2 region");
+};
+
+template <int CH, int CW>
+__global__ __launch_bounds__(256) void k_trunk(const float *__restrict__ in, int B, TrunkParams tp, float *__restrict__ feat) {
+    using G = TrunkGeom<CH, CW>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;  // waves are independent: no workgroup barrier below
+    float *r1 = smem + wave * G::WAVE_FLOATS;  // conv1 output (with zero halo), later conv3 output
+    float *r2 = r1 + NCH * G::PS1;             // padded input plane, later conv2 output
+    for (int i = lane; i < NCH * G::PS1; i += 64) r1[i] = 0.0f;
+    for (int i = lane; i < G::PH * G::PW; i += 64) r2[i] = 0.0f;
+    LDS_FENCE();
+    for (int p = lane; p < G::P1; p += 64) r2[(p / CW + 1) * G::PW + (p % CW) + 1] = in[(size_t)b * G::P1 + p];
+    LDS_FENCE();
+    // conv1 1->32, pad 1 (othello.py:370): one lane per position, scalar weights
+    for (int p = lane; p < G::P1; p += 64) {
+        const int y = p / CW, x = p % CW;
+        float nb[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) nb[t] = r2[(y + t / 3) * G::PW + x + t % 3];
+        for (int oc = 0; oc < NCH; ++oc) {
+            float acc = tp.b1[oc];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = fmaf(nb[t], tp.w1[t * NCH + oc], acc);
+            r1[oc * G::PS1 + (y + 1) * G::PW + x + 1] = acc > 0.0f ? acc : 0.0f;
+        }
+    }
+    LDS_FENCE();
+    {  // conv2 32->32, pad 1 (othello.py:371): reads the halo'd conv1 planes
+        f32x4 acc[G::MT2][2];
+        conv_mfma<G::P1, CW, G::PW, G::PS1, G::MT2>(r1, tp.wf[0], tp.cb[0], lane, acc);
+        LDS_FENCE();
+        store_relu_lds<G::P1, G::PS2, G::MT2>(r2, lane, acc);
+    }
+    LDS_FENCE();
+    {  // conv3 32->32, valid (othello.py:372)
+        f32x4 acc[G::MT3][2];
+        conv_mfma<G::P3, G::W3, CW, G::PS2, G::MT3>(r2, tp.wf[1], tp.cb[1], lane, acc);
+        LDS_FENCE();
+        store_relu_lds<G::P3, G::PS3, G::MT3>(r1, lane, acc);
+    }
+    LDS_FENCE();
+    {  // conv4 32->32, valid (othello.py:373) -> flattened NCHW features (othello.py:374)
+        f32x4 acc[G::MT4][2];
+        conv_mfma<G::P4, G::W4, G::W3, G::PS3, G::MT4>(r1, tp.wf[2], tp.cb[2], lane, acc);
+        float *fo = feat + (size_t)b * (NCH * G::P4);
+#pragma unroll
+        for (int mt = 0; mt < G::MT4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int m = 16 * mt + (lane >> 4) * 4 + r;
+                    float v = acc[mt][nt][r];
+                    if (m < G::P4) fo[(nt * 16 + (lane & 15)) * G::P4 + m] = v > 0.0f ? v : 0.0f;
+                }
+    }
+}
+
+// C[M][N] = act(A[M][K] * Bw[K][N] + bias[N]);  K % 16 == 0, N % BN == 0
+template <int BM, int BN, int WM, int WN, bool RELU>
+__global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const float *__restrict__ Bw,
+                                              const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K) {
+    constexpr int BK = 16, WAVES_N = BN / WN, TM = WM / 16, TN = WN / 16;
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+    constexpr int A_LD = BM / 64, B_LD = BN / 64 > 0 ? BN / 64 : 1;
+    constexpr int BNP = BN + 16;
+    __shared__ float As[BM][BK + 1];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][BNP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        float bv = bias[bn0 + wn0 + tn * 16 + (lane & 15)];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = (f32x4){bv, bv, bv, bv};
+    }
+    float4 ra[A_LD], rb[B_LD];
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            int idx = tid + i * 256, row = idx >> 2, q = idx & 3;
+            int gr = bm0 + row;
+            ra[i] = gr < M ? *reinterpret_cast<const float4 *>(A + (size_t)gr * K + k0 + 4 * q) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            int idx = tid + i * 256;
+            if (BN >= 64 || idx < 4 * BN) {
+                int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+                rb[i] = *reinterpret_cast<const float4 *>(Bw + (size_t)(k0 + kr) * N + bn0 + 4 * c4);
+            }
+        }
+    };
+    issue(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            int idx = tid + i * 256, row = idx >> 2, q = idx & 3;
+            As[row][4 * q + 0] = ra[i].x; As[row][4 * q + 1] = ra[i].y; As[row][4 * q + 2] = ra[i].z; As[row][4 * q + 3] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            int idx = tid + i * 256;
+            if (BN >= 64 || idx < 4 * BN) {
+                int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+                *reinterpret_cast<float4 *>(&Bs[kr][4 * c4]) = rb[i];
+            }
+        }
+        __syncthreads();
+        if (k0 + BK < K) issue(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[tm] = As[wm0 + tm * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = Bs[ks * 4 + (lane >> 4)][wn0 + tn * 16 + (lane & 15)];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA(af[tm], bf[tn], acc[tm][tn]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = bm0 + wm0 + tm * 16 + (lane >> 4) * 4 + r;
+                int col = bn0 + wn0 + tn * 16 + (lane & 15);
+                float v = acc[tm][tn][r];
+                if (RELU) v = v > 0.0f ? v : 0.0f;
+                if (row < M) C[(size_t)row * N + col] = v;
+            }
+}
+
+// policy + value heads (othello.py:379-382, base.py:355): logits = h2 * Wh + bh with
+// Wh = [fc_probs | fc_value | 0-pad] of width NH = 16*NT; then softmax over the first A columns
+// and tanh of column A.  64 rows per block (4 waves x 16 rows).
+template <int NT>
+__global__ __launch_bounds__(256) void k_heads(const float *__restrict__ X, const float *__restrict__ Wh,
+                                               const float *__restrict__ bh, int M, int K, int A,
+                                               float *__restrict__ probs, float *__restrict__ value) {
+    constexpr int NH = NT * 16;
+    __shared__ float Ls[64][NH + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = blockIdx.x * 64 + wave * 16;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { float bv = bh[nt * 16 + (lane & 15)]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
+    int arow = row0 + (lane & 15);
+    arow = arow < M ? arow : M - 1;
+    const float *ap = X + (size_t)arow * K + (lane >> 4);
+    const float *bp = Wh + (size_t)(lane >> 4) * NH + (lane & 15);
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        float a = ap[k0];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA(a, bp[(size_t)k0 * NH + nt * 16], acc[nt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ls[wave * 16 + (lane >> 4) * 4 + r][nt * 16 + (lane & 15)] = acc[nt][r];
+    __syncthreads();
+    if (tid < 64) {
+        int row = blockIdx.x * 64 + tid;
+        if (row < M) {
+            float *l = Ls[tid];
+            float m = l[0];
+            for (int a = 1; a < A; ++a) m = l[a] > m ? l[a] : m;
+            float s = 0.0f;
+            for (int a = 0; a < A; ++a) { float e = az_det_expf(l[a] - m); l[a] = e; s += e; }
+            for (int a = 0; a < A; ++a) probs[(size_t)row * A + a] = l[a] / s;
+            value[row] = az_det_tanhf(l[A]);
+        }
+    }
+}
+
+struct MlpParams { float f1w[81], f1b[9], f2w[81], f2b[9], hw[90], hb[10]; };
+
+__global__ void k_mlp(const float *__restrict__ in, int B, MlpParams p, float *__restrict__ probs, float *__restrict__ value) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float x[9], h1[9], h2[9], lg[10];
+    for (int i = 0; i < 9; ++i) x[i] = in[(size_t)b * 9 + i];
+    for (int j = 0; j < 9; ++j) { float a = p.f1b[j]; for (int k = 0; k < 9; ++k) a = fmaf(x[k], p.f1w[k * 9 + j], a); h1[j] = a > 0.0f ? a : 0.0f; }
+    for (int j = 0; j < 9; ++j) { float a = p.f2b[j]; for (int k = 0; k < 9; ++k) a = fmaf(h1[k], p.f2w[k * 9 + j], a); h2[j] = a > 0.0f ? a : 0.0f; }
+    for (int j = 0; j < 10; ++j) { float a = p.hb[j]; for (int k = 0; k < 9; ++k) a = fmaf(h2[k], p.hw[k * 10 + j], a); lg[j] = a; }
+    float m = lg[0];
+    for (int a = 1; a < 9; ++a) m = lg[a] > m ? lg[a] : m;
+    float s = 0.0f;
+    for (int a = 0; a < 9; ++a) { lg[a] = az_det_expf(lg[a] - m); s += lg[a]; }
+    for (int a = 0; a < 9; ++a) probs[(size_t)b * 9 + a] = lg[a] / s;
+    value[b] = az_det_tanhf(lg[9]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct az_net {
+    int game, H, W, CH, CW, A, F1, F2, FIN, NH, max_batch;
+    std::map<std::string, std::vector<float>> raw;
+    std::vector<void *> allocs;
+    TrunkParams tp;
+    float *fc1w, *fc1b, *fc2w, *fc2b, *hw, *hb;
+    float *feat, *h1, *h2;
+    MlpParams mlp;
+    bool committed;
+};
+
+#define AZ_TRY(x) do { int _rc = (x); if (_rc != AZ_OK) return _rc; } while (0)
+
+static int net_alloc(az_net *n, float **p, size_t count) {
+    void *q = nullptr;
+    AZ_HIP(hipMalloc(&q, count * sizeof(float)));
+    n->allocs.push_back(q);
+    *p = (float *)q;
+    return AZ_OK;
+}
+
+extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out) {
+    AZ_REQUIRE(out && max_batch > 0, AZ_EINVAL, "bad arguments");
+    GameDesc gd;
+    AZ_TRY(az_make_game_desc(game, H, W, &gd));
+    az_net *n = new az_net();
+    n->game = game; n->H = H; n->W = W; n->A = gd.A; n->max_batch = max_batch; n->committed = false;
+    if (game == AZ_OTHELLO) { n->CH = H; n->CW = W; n->F1 = 1024; n->F2 = 512; }       // othello.py:352-358
+    else if (game == AZ_CONNECT4) { n->CH = W; n->CW = H; n->F1 = 64; n->F2 = 32; }     // connect4.py:382-388, 399
+    else { n->CH = 3; n->CW = 3; n->F1 = 9; n->F2 = 9; }
+    n->FIN = game == AZ_TICTACTOE ? 9 : NCH * (n->CH - 4) * (n->CW - 4);
+    n->NH = ((n->A + 1 + 15) / 16) * 16;
+    if (game != AZ_TICTACTOE) {
+        bool ok = (n->CH == 8 && n->CW == 8) || (n->CH == 6 && n->CW == 6) || (n->CH == 7 && n->CW == 6);
+        if (!ok) { delete n; az_set_error("no conv-trunk kernel instantiated for a %dx%d plane", n->CH, n->CW); return AZ_EINVAL; }
+        int rc = AZ_OK;
+        float *p;
+#define NA(field, cnt) if (rc == AZ_OK) { rc = net_alloc(n, &p, (cnt)); field = p; }
+        NA(n->tp.w1, 9 * NCH) NA(n->tp.b1, NCH)
+        for (int l = 0; l < 3; ++l) { NA(n->tp.wf[l], 9 * 8 * 2 * 64) NA(n->tp.cb[l], NCH) }
+        NA(n->fc1w, (size_t)n->FIN * n->F1) NA(n->fc1b, n->F1) NA(n->fc2w, (size_t)n->F1 * n->F2) NA(n->fc2b, n->F2)
+        NA(n->hw, (size_t)n->F2 * n->NH) NA(n->hb, n->NH)
+        NA(n->feat, (size_t)max_batch * n->FIN) NA(n->h1, (size_t)max_batch * n->F1) NA(n->h2, (size_t)max_batch * n->F2)
+#undef NA
+        if (rc != AZ_OK) { az_net_destroy(n); return rc; }
+    }
+    *out = n;
+    return AZ_OK;
+}
+
+extern "C" void az_net_destroy(az_net *n) {
+    if (!n) return;
+    for (void *p : n->allocs) (void)hipFree(p);
+    delete n;
+}
+
+extern "C" int az_net_action_size(const az_net *n) { return n ? n->A : 0; }
+
+extern "C" int64_t az_net_flops_per_board(const az_net *n) {
+    if (!n) return 0;
+    if (n->game == AZ_TICTACTOE) return 2 * (81 + 81 + 90);
+    int64_t p1 = n->CH * n->CW, p3 = (n->CH - 2) * (n->CW - 2), p4 = (n->CH - 4) * (n->CW - 4);
+    int64_t mac = p1 * 9 * NCH + p1 * 9 * NCH * NCH + p3 * 9 * NCH * NCH + p4 * 9 * NCH * NCH;
+    mac += (int64_t)n->FIN * n->F1 + (int64_t)n->F1 * n->F2 + (int64_t)n->F2 * (n->A + 1);
+    return 2 * mac;
+}
+
+extern "C" int az_net_set_tensor(az_net *n, const char *name, const float *h_data, int64_t numel) {
+    AZ_REQUIRE(n && name && h_data && numel > 0, AZ_EINVAL, "bad arguments");
+    n->raw[name] = std::vector<float>(h_data, h_data + numel);
+    n->committed = false;
+    return AZ_OK;
+}
+
+static int need(az_net *n, const std::string &k, size_t numel, const std::vector<float> **out) {
+    auto it = n->raw.find(k);
+    AZ_REQUIRE(it != n->raw.end(), AZ_ESTATE, "missing tensor '%s'", k.c_str());
+    AZ_REQUIRE(it->second.size() == numel, AZ_EINVAL, "tensor '%s' has %zu elements, expected %zu", k.c_str(),
+               it->second.size(), numel);
+    *out = &it->second;
+    return AZ_OK;
+}
+
+#define BN_EPS 1e-5
+
+// s = gamma / sqrt(var + eps);  w' = (float)(w * s);  b' = (float)((b - mean) * s + beta)   [float64]
+static int bn_scale(az_net *n, const std::string &bn, int C, std::vector<double> &s, std::vector<double> &shift_mean,
+                    std::vector<double> &beta) {
+    const std::vector<float> *g, *b, *m, *v;
+    AZ_TRY(need(n, bn + ".weight", C, &g)); AZ_TRY(need(n, bn + ".bias", C, &b));
+    AZ_TRY(need(n, bn + ".running_mean", C, &m)); AZ_TRY(need(n, bn + ".running_var", C, &v));
+    s.resize(C); shift_mean.resize(C); beta.resize(C);
+    for (int i = 0; i < C; ++i) {
+        s[i] = (double)(*g)[i] / sqrt((double)(*v)[i] + BN_EPS);
+        shift_mean[i] = (double)(*m)[i];
+        beta[i] = (double)(*b)[i];
+    }
+    return AZ_OK;
+}
+
+static int upload(float *dst, const std::vector<float> &src, hipStream_t st) {
+    AZ_HIP(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    AZ_HIP(hipStreamSynchronize(st));  // src is a temporary
+    return AZ_OK;
+}
+
+extern "C" int az_net_commit(az_net *n, void *stream) {
+    AZ_REQUIRE(n, AZ_EINVAL, "null net");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<double> s, mean, beta;
+    const std::vector<float> *w, *b;
+    if (n->game == AZ_TICTACTOE) {
+        const char *fc[2] = {"fc1", "fc2"};
+        const char *bn[2] = {"bn1", "bn2"};
+        for (int l = 0; l < 2; ++l) {
+            AZ_TRY(bn_scale(n, bn[l], 9, s, mean, beta));
+            AZ_TRY(need(n, std::string(fc[l]) + ".weight", 81, &w)); AZ_TRY(need(n, std::string(fc[l]) + ".bias", 9, &b));
+            float *fw = l == 0 ? n->mlp.f1w : n->mlp.f2w, *fb = l == 0 ? n->mlp.f1b : n->mlp.f2b;
+            for (int j = 0; j < 9; ++j) {
+                fb[j] = (float)(((double)(*b)[j] - mean[j]) * s[j] + beta[j]);
+                for (int k = 0; k < 9; ++k) fw[k * 9 + j] = (float)((double)(*w)[j * 9 + k] * s[j]);
+            }
+        }
+        const std::vector<float> *pw, *pb, *vw, *vb;
+        AZ_TRY(need(n, "fc_probs.weight", 81, &pw)); AZ_TRY(need(n, "fc_probs.bias", 9, &pb));
+        AZ_TRY(need(n, "fc_value.weight", 9, &vw)); AZ_TRY(need(n, "fc_value.bias", 1, &vb));
+        for (int a = 0; a < 9; ++a) { n->mlp.hb[a] = (*pb)[a]; for (int k = 0; k < 9; ++k) n->mlp.hw[k * 10 + a] = (*pw)[a * 9 + k]; }
+        n->mlp.hb[9] = (*vb)[0];
+        for (int k = 0; k < 9; ++k) n->mlp.hw[k * 10 + 9] = (*vw)[k];
+        n->committed = true;
+        return AZ_OK;
+    }
+    for (int l = 0; l < 4; ++l) {
+        int IC = l == 0 ? 1 : NCH;
+        std::string cn = "conv" + std::to_string(l + 1), bnn = "bn" + std::to_string(l + 1);
+        AZ_TRY(bn_scale(n, bnn, NCH, s, mean, beta));
+        AZ_TRY(need(n, cn + ".weight", (size_t)NCH * IC * 9, &w)); AZ_TRY(need(n, cn + ".bias", NCH, &b));
+        std::vector<float> fb(NCH);
+        for (int oc = 0; oc < NCH; ++oc) fb[oc] = (float)(((double)(*b)[oc] - mean[oc]) * s[oc] + beta[oc]);
+        if (l == 0) {
+            std::vector<float> fw(9 * NCH);
+            for (int oc = 0; oc < NCH; ++oc)
+                for (int t = 0; t < 9; ++t) fw[t * NCH + oc] = (float)((double)(*w)[oc * 9 + t] * s[oc]);
+            AZ_TRY(upload((float *)n->tp.w1, fw, st)); AZ_TRY(upload((float *)n->tp.b1, fb, st));
+        } else {
+            // MFMA B-fragment order: [tap][j][nt][lane] = W'[oc = nt*16 + (lane&15)][ic = 4j + (lane>>4)][tap]
+            std::vector<float> fw(9 * 8 * 2 * 64);
+            for (int t = 0; t < 9; ++t)
+                for (int j = 0; j < 8; ++j)
+                    for (int nt = 0; nt < 2; ++nt)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            int oc = nt * 16 + (lane & 15), ic = 4 * j + (lane >> 4);
+                            fw[((t * 8 + j) * 2 + nt) * 64 + lane] = (float)((double)(*w)[(oc * NCH + ic) * 9 + t] * s[oc]);
+                        }
+            AZ_TRY(upload((float *)n->tp.wf[l - 1], fw, st)); AZ_TRY(upload((float *)n->tp.cb[l - 1], fb, st));
+        }
+    }
+    {
+        AZ_TRY(bn_scale(n, "fc_bn1", n->F1, s, mean, beta));
+        AZ_TRY(need(n, "fc1.weight", (size_t)n->F1 * n->FIN, &w)); AZ_TRY(need(n, "fc1.bias", n->F1, &b));
+        std::vector<float> fw((size_t)n->FIN * n->F1), fb(n->F1);
+        for (int j = 0; j < n->F1; ++j) {
+            fb[j] = (float)(((double)(*b)[j] - mean[j]) * s[j] + beta[j]);
+            for (int k = 0; k < n->FIN; ++k) fw[(size_t)k * n->F1 + j] = (float)((double)(*w)[(size_t)j * n->FIN + k] * s[j]);
+        }
+        AZ_TRY(upload(n->fc1w, fw, st)); AZ_TRY(upload(n->fc1b, fb, st));
+    }
+    {
+        AZ_TRY(bn_scale(n, "fc_bn2", n->F2, s, mean, beta));
+        AZ_TRY(need(n, "fc2.weight", (size_t)n->F2 * n->F1, &w)); AZ_TRY(need(n, "fc2.bias", n->F2, &b));
+        std::vector<float> fw((size_t)n->F1 * n->F2), fb(n->F2);
+        for (int j = 0; j < n->F2; ++j) {
+            fb[j] = (float)(((double)(*b)[j] - mean[j]) * s[j] + beta[j]);
+            for (int k = 0; k < n->F1; ++k) fw[(size_t)k * n->F2 + j] = (float)((double)(*w)[(size_t)j * n->F1 + k] * s[j]);
+        }
+        AZ_TRY(upload(n->fc2w, fw, st)); AZ_TRY(upload(n->fc2b, fb, st));
+    }
+    {
+        const std::vector<float> *pw, *pb, *vw, *vb;
+        AZ_TRY(need(n, "fc_probs.weight", (size_t)n->A * n->F2, &pw)); AZ_TRY(need(n, "fc_probs.bias", n->A, &pb));
+        AZ_TRY(need(n, "fc_value.weight", n->F2, &vw)); AZ_TRY(need(n, "fc_value.bias", 1, &vb));
+        std::vector<float> fw((size_t)n->F2 * n->NH, 0.0f), fb(n->NH, 0.0f);
+        for (int a = 0; a < n->A; ++a) { fb[a] = (*pb)[a]; for (int k = 0; k < n->F2; ++k) fw[(size_t)k * n->NH + a] = (*pw)[(size_t)a * n->F2 + k]; }
+        fb[n->A] = (*vb)[0];
+        for (int k = 0; k < n->F2; ++k) fw[(size_t)k * n->NH + n->A] = (*vw)[k];
+        AZ_TRY(upload(n->hw, fw, st)); AZ_TRY(upload(n->hb, fb, st));
+    }
+    n->committed = true;
+    return AZ_OK;
+}
+
+template <int CH, int CW>
+static int launch_trunk(az_net *n, const float *in, int B, hipStream_t st) {
+    using G = TrunkGeom<CH, CW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk<CH, CW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_trunk<CH, CW>), dim3((B + 3) / 4), dim3(256), G::LDS_BYTES, st, in, B, n->tp, n->feat);
+    return AZ_OK;
+}
+
+static int launch_gemm(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, hipStream_t st) {
+    AZ_REQUIRE(K % 16 == 0, AZ_EINVAL, "GEMM K=%d is not a multiple of 16", K);
+#define GO(BM, BN, WM, WN)                                                                                     \
+    do {                                                                                                       \
+        dim3 grid(N / BN, (M + BM - 1) / BM);                                                                  \
+        if (relu) hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, A, Bw, bias, C, M, N, K);  \
+        else hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, A, Bw, bias, C, M, N, K);     \
+        return AZ_OK;                                                                                          \
+    } while (0)
+    if (N % 128 == 0) {
+        if ((long long)((M + 127) / 128) * (N / 128) >= 256) GO(128, 128, 64, 64);
+        GO(64, 128, 32, 64);
+    }
+    if (N % 64 == 0) GO(128, 64, 32, 64);
+    if (N % 32 == 0) GO(128, 32, 32, 32);
+#undef GO
+    az_set_error("GEMM N=%d is not a multiple of 32", N);
+    return AZ_EINVAL;
+}
+
+static int launch_heads(az_net *n, int B, float *probs, float *value, hipStream_t st) {
+    dim3 grid((B + 63) / 64), bl(256);
+    switch (n->NH / 16) {
+        case 1: hipLaunchKernelGGL((k_heads<1>), grid, bl, 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, probs, value); break;
+        case 3: hipLaunchKernelGGL((k_heads<3>), grid, bl, 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, probs, value); break;
+        case 5: hipLaunchKernelGGL((k_heads<5>), grid, bl, 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, probs, value); break;
+        default: az_set_error("no heads kernel for padded width %d", n->NH); return AZ_EINVAL;
+    }
+    return AZ_OK;
+}
+
+static int run_stage(az_net *n, int stage, const float *d_input, int B, float *d_probs, float *d_value, hipStream_t st) {
+    switch (stage) {
+        case 0:
+            if (n->CH == 8 && n->CW == 8) return launch_trunk<8, 8>(n, d_input, B, st);
+            if (n->CH == 6 && n->CW == 6) return launch_trunk<6, 6>(n, d_input, B, st);
+            return launch_trunk<7, 6>(n, d_input, B, st);
+        case 1: return launch_gemm(n->feat, n->fc1w, n->fc1b, n->h1, B, n->F1, n->FIN, true, st);
+        case 2: return launch_gemm(n->h1, n->fc2w, n->fc2b, n->h2, B, n->F2, n->F1, true, st);
+        default: return launch_heads(n, B, d_probs, d_value, st);
+    }
+}
+
+extern "C" int az_net_forward(az_net *n, const float *d_input, int B, float *d_probs, float *d_value, void *stream) {
+    AZ_REQUIRE(n && d_input && d_probs && d_value, AZ_EINVAL, "null argument");
+    AZ_REQUIRE(n->committed, AZ_ESTATE, "az_net_commit has not been called since the last az_net_set_tensor");
+    AZ_REQUIRE(B > 0 && B <= n->max_batch, AZ_EINVAL, "batch %d outside (0, max_batch=%d]", B, n->max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (n->game == AZ_TICTACTOE) {
+        hipLaunchKernelGGL(k_mlp, dim3((B + 63) / 64), dim3(64), 0, st, d_input, B, n->mlp, d_probs, d_value);
+        return AZ_OK;
+    }
+    for (int s = 0; s < 4; ++s) AZ_TRY(run_stage(n, s, d_input, B, d_probs, d_value, st));
+    return AZ_OK;
+}
+
+extern "C" int az_net_time_stage(az_net *n, int stage, int B, int iters, void *stream, float *ms_per_launch) {
+    AZ_REQUIRE(n && ms_per_launch && iters > 0, AZ_EINVAL, "bad arguments");
+    AZ_REQUIRE(n->committed, AZ_ESTATE, "network not committed");
+    AZ_REQUIRE(B > 0 && B <= n->max_batch, AZ_EINVAL, "batch %d outside (0, max_batch=%d]", B, n->max_batch);
+    AZ_REQUIRE(n->game != AZ_TICTACTOE || stage < 0, AZ_EINVAL, "the TicTacToe MLP has a single stage");
+    hipStream_t st = (hipStream_t)stream;
+    float *in = nullptr, *pr = nullptr, *va = nullptr;
+    AZ_HIP(hipMalloc((void **)&in, (size_t)B * n->H * n->W * sizeof(float)));
+    AZ_HIP(hipMalloc((void **)&pr, (size_t)B * n->A * sizeof(float)));
+    AZ_HIP(hipMalloc((void **)&va, (size_t)B * sizeof(float)));
+    AZ_HIP(hipMemsetAsync(in, 0, (size_t)B * n->H * n->W * sizeof(float), st));
+    hipEvent_t e0, e1;
+    AZ_HIP(hipEventCreate(&e0)); AZ_HIP(hipEventCreate(&e1));
+    int rc = AZ_OK;
+    for (int it = -2; it < iters && rc == AZ_OK; ++it) {  // two untimed warm-up launches
+        if (it == 0) (void)hipEventRecord(e0, st);
+        rc = stage < 0 ? az_net_forward(n, in, B, pr, va, st) : run_stage(n, stage, in, B, pr, va, st);
+    }
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *ms_per_launch = ms / (float)iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(in); (void)hipFree(pr); (void)hipFree(va);
+    return rc;
+}

@@ -1,0 +1,140 @@
+/*
+ * az_amd.h -- C ABI of the MI355X-native AlphaZero self-play engine (libaz_amd.so).
+ *
+ * The reference (t0m1ab/alphazero) is pure Python and has no FFI; its extension surface is the
+ * Board / PolicyValueNetwork / MCT / AlphaZeroTrainer.self_play classes.  Each entry point below
+ * names the reference interface it stands in for (paths relative to /root/reference/alphazero/).
+ * The Python host layer (alphazero_amd/) binds these with ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  `stream` is a hipStream_t passed as
+ *     void* (NULL = default stream).  Pointers prefixed d_ are DEVICE pointers, h_ are HOST pointers.
+ *   - every function returns 0 on success or a negative AZ_E* code and never throws;
+ *     az_last_error() returns the message of the calling thread's last failure.
+ *   - encodings (identical to the reference's numpy objects):
+ *       grid    int8 [H*W] row-major, values {-1,0,+1}      (Board.grid, base.py:112)
+ *       player  int8 in {+1,-1}                              (Board.player)
+ *       action  othello r*n+c, pass = n*n; tictactoe 3r+c; connect4 column
+ *               (PolicyValueNetwork.to_neural_output, othello.py:404-412, connect4.py:430-435)
+ *   - an engine handle is not re-entrant; different handles may be driven from different threads.
+ */
+#ifndef AZ_AMD_H
+#define AZ_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_GAME_OTHELLO 0
+#define AZ_GAME_CONNECT4 1
+#define AZ_GAME_TICTACTOE 2
+
+#define AZ_OK 0
+#define AZ_EINVAL (-1)   /* bad argument (reference: ValueError in constructors) */
+#define AZ_EHIP (-2)     /* HIP runtime failure */
+#define AZ_ESTATE (-3)   /* call order / missing weights */
+#define AZ_ECAPACITY (-4)/* node pool or sample buffer exhausted */
+#define AZ_EILLEGAL (-5) /* illegal move (reference: ValueError, othello.py:199-200) */
+
+#define AZ_TIE_MODE_LOWEST 0  /* fair_max ties -> lowest action index (deterministic, tests) */
+#define AZ_TIE_MODE_RANDOM 1  /* fair_max ties -> uniform (utils.py:28-34), Philox stream */
+#define AZ_NOISE_MODE_OFF 0
+#define AZ_NOISE_MODE_PHILOX 1 /* root Dirichlet noise (mcts.py:235-240) from the Philox stream */
+#define AZ_NOISE_MODE_HASH 2   /* closed-form noise from the root board hash (tests) */
+#define AZ_EVAL_NET 0          /* PolicyValueNetwork.evaluate (base.py:357-367) on the HIP network */
+#define AZ_EVAL_FAKE 1         /* closed-form fake network (tests; tools/closed_form.py) */
+
+const char *az_last_error(void);
+int az_version(void);
+
+/* ---- batched board rules (K1/K2) -------------------------------------------------------------
+ * replaces Board.get_moves / is_legal_move / play_move / is_game_over / get_winner / get_score
+ * (othello.py:133-229, connect4.py:143-258, tictactoe.py:139-184) for n positions at once. */
+
+/* d_legal[n][A] uint8: 1 where the action is legal for `d_for_player[i]` (0 = side to move,
+ * base.py:163-171 `player` argument).  d_for_player may be NULL. */
+int az_board_legal_batch(int game, int H, int W, const int8_t *d_grids, const int8_t *d_players,
+                         const int8_t *d_for_player, int64_t n, uint8_t *d_legal, void *stream);
+/* plays d_actions[i]; d_status[i] = 0 ok / AZ_EILLEGAL (board then copied unchanged). */
+int az_board_play_batch(int game, int H, int W, const int8_t *d_grids, const int8_t *d_players,
+                        const int32_t *d_actions, int64_t n, int8_t *d_out_grids, int8_t *d_out_players,
+                        int32_t *d_status, void *stream);
+/* d_over[i] uint8, d_winner[i] int8 (valid where over; 2 otherwise), d_score[i] int32 =
+ * sum(player*grid) (Board.get_score of othello/connect4). */
+int az_board_status_batch(int game, int H, int W, const int8_t *d_grids, const int8_t *d_players, int64_t n,
+                          uint8_t *d_over, int8_t *d_winner, int32_t *d_score, void *stream);
+
+/* ---- policy-value network (K5/K6) ------------------------------------------------------------
+ * replaces OthelloNet / Connect4Net / TicTacToeNet .forward + PolicyValueNetwork.predict
+ * (othello.py:341-382, connect4.py:370-412, tictactoe.py:289-316, base.py:350-355), eval mode. */
+typedef struct az_net az_net;
+int az_net_create(int game, int H, int W, int max_batch, az_net **out);
+void az_net_destroy(az_net *net);
+/* h_data: HOST float32 tensor of the torch state_dict entry `name` ("conv1.weight",
+ * "bn1.running_var", "fc_probs.bias", ...).  Unknown keys (num_batches_tracked) return AZ_OK. */
+int az_net_set_tensor(az_net *net, const char *name, const float *h_data, int64_t numel);
+/* folds eval-mode BatchNorm into the preceding layer (float64), re-tiles the weights into MFMA
+ * fragment order and uploads them.  Must be called after all tensors are set / updated. */
+int az_net_commit(az_net *net, void *stream);
+/* d_input[B][H*W] float32 canonical boards (player*grid, base.py:363);
+ * d_probs[B][A] = exp(log_softmax) policy, d_value[B] = tanh value. */
+int az_net_forward(az_net *net, const float *d_input, int B, float *d_probs, float *d_value, void *stream);
+int az_net_action_size(const az_net *net);
+/* algorithmic FLOPs of one forward per board (2*MAC) */
+int64_t az_net_flops_per_board(const az_net *net);
+/* times `iters` back-to-back launches of one forward stage with HIP events on `stream`;
+ * stage: 0 conv trunk, 1 fc1, 2 fc2, 3 heads, -1 whole forward.  *ms_per_launch out. */
+int az_net_time_stage(az_net *net, int stage, int B, int iters, void *stream, float *ms_per_launch);
+
+/* ---- self-play engine (K3/K4/K7/K8/K9) -------------------------------------------------------
+ * replaces AlphaZeroTrainer.self_play (trainer.py:215-273) driving AlphaZeroPlayer.get_move
+ * (players.py:158-191) / MCT.search (mcts.py:226-269) for n_slots concurrent games in lock-step. */
+typedef struct az_engine az_engine;
+typedef struct {
+    int32_t game, H, W;
+    int32_t n_slots;           /* concurrent games resident in HBM */
+    int32_t n_sim;             /* Config.simulations */
+    double dirichlet_alpha;    /* < 0 : None */
+    double dirichlet_epsilon;  /* < 0 : None */
+    int32_t temp_max_step, temp_min_step; /* LinearTemperatureScheduler (schedulers.py:20-40) */
+    int32_t tie_mode, noise_mode, evaluator;
+    uint32_t seed;             /* Philox key word 0; word 1 is the game id */
+    int32_t node_capacity;     /* tree nodes per slot (bump-allocated per game) */
+    int32_t max_plies;         /* per game, sample staging */
+    int64_t sample_capacity;   /* samples the output buffers can hold */
+} az_engine_cfg;
+
+typedef struct {
+    int64_t games_done, samples, net_evals, lockstep_iters, plies;
+    int32_t max_nodes_used, error_flags;
+} az_engine_stats;
+
+int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *stream, az_engine **out);
+void az_engine_destroy(az_engine *e);
+/* plays games first_game_id .. first_game_id+n_games-1 to completion (slots are refilled as games
+ * end) and blocks until done.  Samples accumulate in the output buffers from index 0. */
+int az_engine_run(az_engine *e, uint32_t first_game_id, int32_t n_games);
+int az_engine_get_stats(az_engine *e, az_engine_stats *out);
+/* device views of the normalised samples (trainer.py:262-265, Sample.normalize):
+ *   states int8 [S][H*W] = grid*player, pis float32 [S][A], zs int8 [S] = winner*player,
+ *   meta int32 [S][4] = {game_id, move_idx, player, action}, visits int32 [S][A]. */
+int az_engine_samples(az_engine *e, int64_t *n_samples, const int8_t **d_states, const float **d_pis,
+                      const int8_t **d_zs, const int32_t **d_meta, const int32_t **d_visits);
+
+/* finer-grained control (tests, arena-style use): */
+/* puts n_roots positions into slots 0..n-1 (fresh trees); h_* are HOST arrays. */
+int az_engine_set_roots(az_engine *e, const int8_t *h_grids, const int8_t *h_players, const uint32_t *h_game_ids,
+                        const int32_t *h_plies, int32_t n_roots);
+int az_engine_search(az_engine *e, int32_t n_sim);     /* MCT.search on every active slot */
+/* MCT.get_action_probs + sampled move + Board.play_move + MCT.change_root (+ sample record) */
+int az_engine_advance(az_engine *e);
+/* root statistics of one slot to HOST arrays (capacity AZ_MAX 65): actions, N, Q, P */
+int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_actions, int32_t *h_N, double *h_Q,
+                            double *h_P, int32_t *count, int32_t *root_N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1041,3 +1041,76 @@ int64_t orc_selfplay(const orc_selfplay_cfg *cfg, orc_eval_fn eval, void *eval_c
     orc_mct_destroy(t);
     return S;
 }
+
+/* ======================================================================== */
+/* batch helpers (tests compare whole arrays against the HIP kernels)         */
+/* ======================================================================== */
+
+static void load_board(orc_board *b, int game, int H, int W, const int8_t *grid, int player) {
+    memset(b, 0, sizeof(*b));
+    b->game = game; b->H = H; b->W = W; b->player = player;
+    memcpy(b->grid, grid, (size_t)(H * W));
+}
+
+void orc_batch_legal(int game, int H, int W, const int8_t *grids, const int8_t *players, const int8_t *for_player,
+                     int64_t n, uint8_t *legal) {
+    orc_board b;
+    int mv[ORC_MAX_ACTIONS];
+    for (int64_t i = 0; i < n; ++i) {
+        load_board(&b, game, H, W, grids + i * H * W, players[i]);
+        int A = orc_action_size(&b);
+        memset(legal + i * A, 0, (size_t)A);
+        int k = orc_legal_moves(&b, for_player ? for_player[i] : 0, mv);
+        for (int j = 0; j < k; ++j) legal[i * A + mv[j]] = 1;
+    }
+}
+
+void orc_batch_play(int game, int H, int W, const int8_t *grids, const int8_t *players, const int32_t *actions, int64_t n,
+                    int8_t *out_grids, int8_t *out_players, int32_t *status) {
+    orc_board b;
+    for (int64_t i = 0; i < n; ++i) {
+        load_board(&b, game, H, W, grids + i * H * W, players[i]);
+        status[i] = orc_play(&b, actions[i]) == 0 ? 0 : -5;
+        memcpy(out_grids + i * H * W, b.grid, (size_t)(H * W));
+        out_players[i] = (int8_t)b.player;
+    }
+}
+
+void orc_batch_status(int game, int H, int W, const int8_t *grids, const int8_t *players, int64_t n, uint8_t *over,
+                      int8_t *winner, int32_t *score) {
+    orc_board b;
+    for (int64_t i = 0; i < n; ++i) {
+        load_board(&b, game, H, W, grids + i * H * W, players[i]);
+        int w = 2;
+        over[i] = (uint8_t)orc_is_over(&b);
+        if (over[i]) orc_winner(&b, &w);
+        winner[i] = (int8_t)(over[i] ? w : 2);
+        int s = 0;
+        for (int c = 0; c < H * W; ++c) s += b.player * b.grid[c];
+        score[i] = s;
+    }
+}
+
+/* random playouts: records every position reached (for large-scale GPU parity sweeps) */
+int64_t orc_random_positions(int game, int H, int W, uint32_t seed, int n_games, int64_t cap, int8_t *grids, int8_t *players,
+                             int32_t *actions) {
+    int64_t n = 0;
+    int mv[ORC_MAX_ACTIONS];
+    for (int g = 0; g < n_games; ++g) {
+        orc_board b;
+        orc_board_init(&b, game, H, W);
+        uint32_t step = 0;
+        while (!orc_is_over(&b) && n < cap) {
+            int k = orc_legal_moves(&b, 0, mv);
+            uint32_t r[4];
+            orc_philox4x32(seed, (uint32_t)g, step++, 0, 99, 0, r);
+            int a = mv[(uint32_t)(((uint64_t)r[0] * (uint32_t)k) >> 32)];
+            memcpy(grids + n * H * W, b.grid, (size_t)(H * W));
+            players[n] = (int8_t)b.player;
+            actions[n] = a;
+            n++;
+            orc_play(&b, a);
+        }
+    }
+    return n;
+}

@@ -143,6 +143,16 @@ int64_t orc_selfplay(const orc_selfplay_cfg *cfg, orc_eval_fn eval, void *eval_c
                      uint32_t first_game_id, int n_games, int64_t max_samples, int8_t *states,
                      float *pis, int8_t *zs, int32_t *meta, int32_t *visits, int64_t *n_evals);
 
+/* ---- batch helpers for array-wise comparison with the HIP kernels ---------- */
+void orc_batch_legal(int game, int H, int W, const int8_t *grids, const int8_t *players, const int8_t *for_player,
+                     int64_t n, uint8_t *legal);
+void orc_batch_play(int game, int H, int W, const int8_t *grids, const int8_t *players, const int32_t *actions, int64_t n,
+                    int8_t *out_grids, int8_t *out_players, int32_t *status);
+void orc_batch_status(int game, int H, int W, const int8_t *grids, const int8_t *players, int64_t n, uint8_t *over,
+                      int8_t *winner, int32_t *score);
+int64_t orc_random_positions(int game, int H, int W, uint32_t seed, int n_games, int64_t cap, int8_t *grids, int8_t *players,
+                             int32_t *actions);
+
 #ifdef __cplusplus
 }
 #endif

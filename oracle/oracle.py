@@ -116,6 +116,12 @@ def lib():
     L.orc_selfplay.argtypes = [C.POINTER(SelfplayCfg), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     L.orc_selfplay.restype = C.c_int64
+    vp = C.c_void_p
+    L.orc_batch_legal.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, vp]
+    L.orc_batch_play.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int64, vp, vp, vp]
+    L.orc_batch_status.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64, vp, vp, vp]
+    L.orc_random_positions.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int64, vp, vp, vp]
+    L.orc_random_positions.restype = C.c_int64
     _LIB = L
     return L
 
@@ -283,3 +289,43 @@ def selfplay(game_id, H, W, n_games, n_sim, evaluator=("fake", None), alpha=0.03
         raise RuntimeError("oracle selfplay failed")
     return {"state": states[:S].reshape(S, H, W), "pi": pis[:S], "z": zs[:S], "meta": meta[:S],
             "visits": visits[:S], "n_evals": n_evals.value}
+
+
+def action_size(game_id, H, W):
+    return H * W + 1 if game_id == OTHELLO else (W if game_id == CONNECT4 else 9)
+
+
+def batch_legal(game_id, H, W, grids, players, for_player=None):
+    grids = np.ascontiguousarray(grids, np.int8).reshape(-1, H * W); players = np.ascontiguousarray(players, np.int8)
+    n, A = len(players), action_size(game_id, H, W)
+    out = np.zeros((n, A), np.uint8)
+    fp = np.ascontiguousarray(for_player, np.int8) if for_player is not None else None
+    lib().orc_batch_legal(game_id, H, W, grids.ctypes.data, players.ctypes.data, fp.ctypes.data if fp is not None else None,
+                          n, out.ctypes.data)
+    return out
+
+
+def batch_play(game_id, H, W, grids, players, actions):
+    grids = np.ascontiguousarray(grids, np.int8).reshape(-1, H * W); players = np.ascontiguousarray(players, np.int8)
+    actions = np.ascontiguousarray(actions, np.int32)
+    n = len(players)
+    og = np.zeros_like(grids); op = np.zeros_like(players); st = np.zeros(n, np.int32)
+    lib().orc_batch_play(game_id, H, W, grids.ctypes.data, players.ctypes.data, actions.ctypes.data, n, og.ctypes.data,
+                         op.ctypes.data, st.ctypes.data)
+    return og, op, st
+
+
+def batch_status(game_id, H, W, grids, players):
+    grids = np.ascontiguousarray(grids, np.int8).reshape(-1, H * W); players = np.ascontiguousarray(players, np.int8)
+    n = len(players)
+    over = np.zeros(n, np.uint8); win = np.zeros(n, np.int8); score = np.zeros(n, np.int32)
+    lib().orc_batch_status(game_id, H, W, grids.ctypes.data, players.ctypes.data, n, over.ctypes.data, win.ctypes.data,
+                           score.ctypes.data)
+    return over, win, score
+
+
+def random_positions(game_id, H, W, seed, n_games, cap):
+    grids = np.zeros((cap, H * W), np.int8); players = np.zeros(cap, np.int8); actions = np.zeros(cap, np.int32)
+    n = lib().orc_random_positions(game_id, H, W, seed, n_games, cap, grids.ctypes.data, players.ctypes.data,
+                                   actions.ctypes.data)
+    return grids[:n], players[:n], actions[:n]

@@ -1,0 +1,46 @@
+"""CPU-only checks of the C ABI: the library loads and exports every symbol include/az_amd.h declares,
+and argument validation (no GPU call) maps to the reference's exceptions."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from alphazero_amd import _lib
+
+
+def test_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "az_amd.h")).read()
+    declared = set(re.findall(r"\b(az_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = _lib.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(_lib.SYMBOLS)
+    assert L.az_version() >= 100
+
+
+def test_constructor_errors_match_reference():
+    L = _lib.lib()
+    h = C.c_void_p()
+    # othello.py:87-88 : odd board size
+    with pytest.raises(ValueError, match="Board size must be even"):
+        _lib.check(L.az_net_create(0, 5, 5, 16, C.byref(h)))
+    # connect4.py:90-91 : smaller than 4x4
+    with pytest.raises(ValueError, match="at least 4x4"):
+        _lib.check(L.az_net_create(1, 3, 7, 16, C.byref(h)))
+    cfg = _lib.EngineCfg(0, 8, 8, 4, 10, 0.03, 0.25, 5, 4, 0, 0, 1, 0, 4096, 128, 1024)
+    # schedulers.py:29-30 : temp_min_step < temp_max_step
+    with pytest.raises(ValueError, match="temp_min_step"):
+        _lib.check(L.az_engine_create(C.byref(cfg), None, None, C.byref(h)))
+
+
+def test_product_does_not_import_oracle():
+    """the oracle is test infrastructure: nothing under alphazero_amd/ may reference it"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "alphazero_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("CPU oracle", "").replace("the oracle", "").lower() or f.endswith((".hip", ".h")), f
+                assert "liboracle" not in src and "az_oracle" not in src, f
