@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Headline benchmark: self-play games/s, Othello 8x8 @ 100 sims/move (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one self-play wave: every rank plays `--games` (default 4096) concurrent Othello 8x8
+games from the start position to the end at 100 MCTS simulations per move through the HIP engine
+(random-init OthelloNet(n=8) under torch.manual_seed(0), Dirichlet noise 0.03/0.25, tau linear(4,4),
+tree reuse) and, for N > 1, all-gathers the samples over RCCL.  value = games of all ranks / time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+STAGE_NAMES = ["k_trunk (conv1-4)", "k_gemm fc1", "k_gemm fc2", "k_heads"]
+
+
+def stage_flops(n):
+    conv = 2 * (n * n * 9 * 32 + n * n * 9 * 32 * 32 + (n - 2) ** 2 * 9 * 32 * 32 + (n - 4) ** 2 * 9 * 32 * 32)
+    fin = 32 * (n - 4) ** 2
+    return [conv, 2 * fin * 1024, 2 * 1024 * 512, 2 * 512 * (n * n + 2)]
+
+
+def cpu_baseline(state_dict, n_games=3, n_sim=100):
+    """the CPU oracle (C port of the reference's self-play loop) on one host core, same weights/config"""
+    from oracle import oracle as O
+    net = O.ConvNet(O.OTHELLO, 8, 8, {k: v.cpu().numpy() for k, v in state_dict.items() if not k.endswith("num_batches_tracked")})
+    t0 = time.perf_counter()
+    r = O.selfplay(O.OTHELLO, 8, 8, n_games, n_sim, ("conv", net), seed=0)
+    dt = time.perf_counter() - t0
+    return {"value": n_games / dt, "unit": "games/s", "cores": 1, "kind": "port",
+            "sample": f"{n_games} full Othello 8x8 self-play games at {n_sim} sims/move ({len(r['z'])} plies, "
+                      f"{r['n_evals']} net evals) on 1 host core, oracle/liboracle.so",
+            "examples_per_sec": len(r["z"]) / dt, "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU (= games per step per GPU)")
+    ap.add_argument("--sims", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from alphazero_amd import engine as E
+    from alphazero_amd.dist import all_gather_samples, rank_game_range
+    from alphazero_amd.games.othello import OthelloNet
+
+    n, G = 8, args.games
+    torch.manual_seed(0)
+    model = OthelloNet(n=n).eval()
+    hnet = model.to_hip(max_batch=G)
+    eng = E.SelfPlayEngine(0, n, n, n_slots=G, n_sim=args.sims, net=hnet, dirichlet_alpha=0.03, dirichlet_epsilon=0.25,
+                           temp_max_step=4, temp_min_step=4, tie_mode=E.TIE_RANDOM, noise_mode=E.NOISE_PHILOX,
+                           seed=0, node_capacity=98304, max_plies=128, sample_capacity=G * 72)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step(wave):
+        first, cnt = rank_game_range(rank, world, G, wave)
+        eng.run(cnt, first_game_id=first)
+        smp = eng.samples(copy=False)
+        if world > 1:
+            smp = all_gather_samples({k: smp[k] for k in ("state", "pi", "z", "meta")})
+        return smp["z"].shape[0]
+
+    for w in range(args.warmup):
+        step(w)
+    sync()
+    t0 = time.perf_counter()
+    n_samples_total = 0
+    for k in range(args.steps):
+        n_samples_total += step(args.warmup + k)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    st = eng.stats()
+
+    if rank == 0:
+        games = args.steps * G * world
+        samples = n_samples_total  # after the all-gather every rank holds all ranks' samples
+        out = {
+            "metric": "self-play games/sec (whole node), Othello 8x8 @100 sims/move", "value": games / dt, "unit": "games/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Othello 8x8, {G} concurrent self-play games per GPU, {args.sims} sims/move, "
+                                   f"random-init OthelloNet(n=8) seed 0, Dirichlet 0.03/0.25, tau linear(4,4), tree reuse",
+                       "games_per_gpu_per_step": G, "sims_per_move": args.sims, "parallelism": f"game-sharded x{world}"},
+            "examples_per_sec": samples / dt, "sims_per_sec": samples * args.sims / dt,
+            "plies_per_game": samples / games, "net_evals_last_step": st["net_evals"], "lockstep_iters_last_step": st["lockstep_iters"],
+            "max_tree_nodes_per_game": st["max_nodes_used"],
+        }
+        # roofline of the dominant kernel: per-launch time measured here with HIP events on the engine's stream
+        fl = stage_flops(n)
+        ms = [hnet.time_stage(s, G, iters=30) for s in range(4)]
+        dom = int(np.argmax(ms))
+        ach = fl[dom] * G / (ms[dom] * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(STAGE_NAMES[dom].split()[0] + ("_" + STAGE_NAMES[dom].split()[1] if dom in (1, 2) else ""))
+        out["roofline"] = {"bound": "mfma", "kernel": STAGE_NAMES[dom], "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                           "launch_ms": ms[dom], "algorithmic_flops_per_launch": fl[dom] * G,
+                           "all_stages_ms": dict(zip(STAGE_NAMES, ms)),
+                           "forward_tflops": sum(fl) * G / (sum(ms) * 1e-3) / 1e12}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model.state_dict())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
