@@ -4,19 +4,23 @@
 // batch for the policy-value network.  Every tree still sees strictly sequential simulations, so
 // per-game semantics equal the reference's MCT.search (mcts.py:226-269) exactly -- no virtual loss.
 //
-// HBM layout (struct of arrays, all indexed [slot] or [slot][node]):
-//   boards   : 2 x u64 bitboards + int8 side-to-move per slot (root and current leaf)
-//   tree     : per-slot bump-allocated node pool of `C` nodes; a node's children are contiguous
-//              N:i32  Q:f64  P:f64  parent:i32  first_child:i32  n_children:u8  action:u8  flags:u8  winner:i8
+// HBM layout
+//   boards   : 2 x u64 bitboards + int8 side-to-move per slot (root and current leaf), SoA over slots
+//   tree     : per-slot bump-allocated pool of `C` 32-byte nodes (one node = two 16-byte accesses;
+//              a node's children are contiguous, so 16 lanes read 16 children as one 512-byte run):
+//              { f64 Q, f64 P, i32 N, i32 parent, i32 first_child, u8 n_children, u8 action, u8 flags, i8 winner }
 //   net i/o  : nn_in[G][cells] f32 canonical leaf boards, probs[G][A] f32, value[G] f32
 //   samples  : state i8[S][cells], pi f32[S][A], z i8[S], meta i32[S][4], visits i32[S][A]
+//
+// Mapping: 16 lanes per game (4 games per wavefront, 16 per 256-thread block).  PUCT scoring, prior
+// renormalisation, child creation and Dirichlet draws are spread over the 16 lanes (one child
+// each); arg-max / tie counting use width-16 shuffles and wave ballots; the board of the walk is
+// replicated in the group's registers and advanced with bitboard shifts.
 //
 // Lazy expansion (mcts.py:151-160) is kept observable-equivalent with eager allocation: when a leaf
 // is evaluated its children are created at once from the renormalised priors but stay invisible
 // (flag F_EXPANDED clear) until the node's next visit, which is when the reference materialises
 // them.  This stores n_children priors per evaluated node instead of the raw probs[A] vector.
-//
-// v1 mapping: one thread per game (the net forward dominates the step).
 #include <string.h>
 
 #include <vector>
@@ -39,7 +43,18 @@
 #define ERR_PLY_CAP 4
 #define ERR_INTERNAL 8
 
+#define LPG 16          // lanes per game
+#define GPB (256 / LPG) // games per 256-thread block
+
 enum { CTR_SAMPLES = 0, CTR_GAMES_DONE, CTR_NET_EVALS, CTR_NEXT_GAME, CTR_TOTAL_GAMES, CTR_FIRST_ID, CTR_PLIES, CTR_COUNT };
+
+struct __attribute__((aligned(16))) Node {
+    double Q, P;
+    int N, parent, first;
+    uint8_t nch, act, flags;
+    int8_t win;
+};
+static_assert(sizeof(Node) == 32, "node is two 16-byte accesses");
 
 struct EngDev {
     GameDesc gd;
@@ -51,7 +66,7 @@ struct EngDev {
     u64 *root_p1, *root_m1; int8_t *root_player;
     int *root, *n_nodes, *ply; u32 *game_id; uint8_t *active, *root_fresh;
     int *leaf; u64 *leaf_p1, *leaf_m1; int8_t *leaf_player, *leaf_status, *leaf_winner;
-    int *nN; double *nQ, *nP; int *nparent, *nfirst; uint8_t *nnch, *nact, *nflags; int8_t *nwin;
+    Node *nodes;
     float *nn_in, *probs, *value;
     int *samp_idx;
     int8_t *o_state; float *o_pi; int8_t *o_z; int *o_meta, *o_visits;
@@ -60,11 +75,50 @@ struct EngDev {
 };
 
 // ---------------------------------------------------------------------------------------------
-// device helpers
+// node access (two 16-byte transactions) and 16-lane group primitives
 // ---------------------------------------------------------------------------------------------
-AZ_D void init_node(const EngDev &E, size_t i, int action, int parent, double P, int flags) {
-    E.nN[i] = 0; E.nQ[i] = 0.0; E.nP[i] = P; E.nparent[i] = parent; E.nfirst[i] = -1;
-    E.nnch[i] = 0; E.nact[i] = (uint8_t)action; E.nflags[i] = (uint8_t)flags; E.nwin[i] = 0;
+AZ_D Node load_node(const Node *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Node n;
+    n.Q = __longlong_as_double((long long)(((u64)a.y << 32) | a.x));
+    n.P = __longlong_as_double((long long)(((u64)a.w << 32) | a.z));
+    n.N = (int)b.x; n.parent = (int)b.y; n.first = (int)b.z;
+    n.nch = (uint8_t)(b.w & 0xff); n.act = (uint8_t)((b.w >> 8) & 0xff); n.flags = (uint8_t)((b.w >> 16) & 0xff);
+    n.win = (int8_t)(b.w >> 24);
+    return n;
+}
+
+AZ_D void store_node(Node *p, const Node &n) {
+    u64 q = (u64)__double_as_longlong(n.Q), pp = (u64)__double_as_longlong(n.P);
+    uint4 a = make_uint4((u32)q, (u32)(q >> 32), (u32)pp, (u32)(pp >> 32));
+    uint4 b = make_uint4((u32)n.N, (u32)n.parent, (u32)n.first,
+                         (u32)n.nch | ((u32)n.act << 8) | ((u32)n.flags << 16) | ((u32)(uint8_t)n.win << 24));
+    uint4 *d = reinterpret_cast<uint4 *>(p);
+    d[0] = a; d[1] = b;
+}
+
+AZ_D Node fresh_node(int action, int parent, double P, int flags) {
+    Node n;
+    n.Q = 0.0; n.P = P; n.N = 0; n.parent = parent; n.first = -1; n.nch = 0; n.act = (uint8_t)action;
+    n.flags = (uint8_t)flags; n.win = 0;
+    return n;
+}
+
+AZ_D u32 grp_ballot(bool p) { return (u32)(__ballot(p) >> (threadIdx.x & 48)) & 0xFFFFu; }
+AZ_D double grp_max(double v) {
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, LPG));
+    return v;
+}
+AZ_D u64 grp_sum_u64(u64 v) {
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v += (u64)__shfl_xor((long long)v, m, LPG);
+    return v;
+}
+AZ_D int kth_set_bit(u32 mask, int k) {
+    for (int i = 0; i < k; ++i) mask &= mask - 1;
+    return __ffs((int)mask) - 1;
 }
 
 AZ_D void start_position(const GameDesc &gd, BB &b) {
@@ -76,65 +130,80 @@ AZ_D void start_position(const GameDesc &gd, BB &b) {
     }
 }
 
-AZ_D void write_nn_input(const EngDev &E, int g, const BB &b) {  // base.py:363 : player * grid
+// base.py:363 : player * grid, spread over the group's lanes (coalesced row of `cells` floats)
+AZ_D void write_nn_input_grp(const EngDev &E, int g, const BB &b, int sub) {
     float *dst = E.nn_in + (size_t)g * E.gd.cells;
-    for (int r = 0; r < E.gd.H; ++r)
-        for (int c = 0; c < E.gd.W; ++c) dst[r * E.gd.W + c] = (float)(b.player * az_cell_value(b, r, c));
+    for (int i = sub; i < E.gd.cells; i += LPG) dst[i] = (float)(b.player * az_cell_value(b, i / E.gd.W, i % E.gd.W));
 }
 
-// get_normalized_probs (othello.py:384-402, connect4.py:414-428, tictactoe.py:318-334) + add_child
-AZ_D int create_children(const EngDev &E, int g, int node, const BB &bb, const float *pr) {
+// get_normalized_probs (othello.py:384-402, connect4.py:414-428, tictactoe.py:318-334) + add_child,
+// one lane per legal action bit; returns false on pool exhaustion
+AZ_D bool create_children_grp(const EngDev &E, int g, int node, const BB &bb, const float *pr, int sub) {
     const GameDesc &gd = E.gd;
-    size_t base = (size_t)g * E.C;
+    Node *pool = E.nodes + (size_t)g * E.C;
     u64 bits = az_legal_bits(gd, bb, bb.player);
     bool pass = (gd.game == AZ_OTHELLO && bits == 0);
     int k = pass ? 1 : __popcll(bits);
     int fc = E.n_nodes[g];
-    if (k <= 0 || fc + k > E.C) { atomicOr(E.err, k <= 0 ? ERR_INTERNAL : ERR_NODE_POOL); return -1; }
-    E.n_nodes[g] = fc + k;
-    atomicMax(E.max_nodes, fc + k);
-    float s = 0.0f;  // float32 running sum in ascending action order
+    if (k <= 0 || fc + k > E.C) { if (sub == 0) atomicOr(E.err, k <= 0 ? ERR_INTERNAL : ERR_NODE_POOL); return false; }
+    float s = 0.0f;  // float32 running sum in ascending action order (every lane, same result)
     if (pass) s += pr[gd.A - 1];
     else for (u64 m = bits; m; m &= m - 1) s += pr[az_bit_to_action(gd, __ffsll((long long)m) - 1)];
     bool uniform = s < 1e-6f;
-    int i = 0;
     if (pass) {
-        init_node(E, base + fc, gd.A - 1, node, uniform ? 1.0 : (double)(pr[gd.A - 1] / s), uniform ? 0 : F_PF32);
+        if (sub == 0) store_node(pool + fc, fresh_node(gd.A - 1, node, uniform ? 1.0 : (double)(pr[gd.A - 1] / s), uniform ? 0 : F_PF32));
     } else {
-        for (u64 m = bits; m; m &= m - 1, ++i) {
-            int a = az_bit_to_action(gd, __ffsll((long long)m) - 1);
-            init_node(E, base + fc + i, a, node, uniform ? 1.0 / (double)k : (double)(pr[a] / s), uniform ? 0 : F_PF32);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int bit = r * LPG + sub;
+            if ((bits >> bit) & 1ULL) {
+                int idx = __popcll(bits & ((1ULL << bit) - 1ULL));
+                int a = az_bit_to_action(gd, bit);
+                store_node(pool + fc + idx, fresh_node(a, node, uniform ? 1.0 / (double)k : (double)(pr[a] / s), uniform ? 0 : F_PF32));
+            }
         }
     }
-    E.nfirst[base + node] = fc;
-    E.nnch[base + node] = (uint8_t)k;
-    E.nflags[base + node] |= F_EVALUATED;
-    return 0;
+    if (sub == 0) {
+        E.n_nodes[g] = fc + k;
+        atomicMax(E.max_nodes, fc + k);
+        pool[node].first = fc;
+        pool[node].nch = (uint8_t)k;
+        pool[node].flags |= F_EVALUATED;
+    }
+    return true;
 }
 
-// fair_max over PUCT (mcts.py:44-46, 137; utils.py:28-34)
-AZ_D int pick_child(const EngDev &E, int g, int node, int ply, int sim, int depth) {
-    size_t base = (size_t)g * E.C;
-    int fc = E.nfirst[base + node], nc = E.nnch[base + node];
-    double sq = sqrt((double)E.nN[base + node]);
-    double best = -__builtin_inf();
-    int cnt = 0, first = 0;
-    for (int i = 0; i < nc; ++i) {
-        size_t c = base + fc + i;
-        double key = E.nQ[c] + (E.nP[c] * sq) / (double)(1 + E.nN[c]);
-        if (key > best) { best = key; cnt = 1; first = i; }
-        else if (key == best) cnt++;
+// fair_max over PUCT (mcts.py:44-46, 137; utils.py:28-34): one lane per child, 16 children per round
+AZ_D int pick_child_grp(const EngDev &E, int g, const Node *pool, const Node &parent, int ply, int sim, int depth, int sub) {
+    const int fc = parent.first, nc = parent.nch;
+    const double sq = sqrt((double)parent.N);
+    double key[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        key[r] = -__builtin_inf();
+        int i = r * LPG + sub;
+        if (i < nc) {
+            Node c = load_node(pool + fc + i);
+            key[r] = c.Q + (c.P * sq) / (double)(1 + c.N);
+        }
     }
-    if (E.tie_mode == AZ_TIE_LOWEST) return fc + first;
-    Philox4 r = az_philox(E.seed, E.game_id[g], (u32)ply, (u32)sim, AZ_P_TIE_SELECT, (u32)depth);
-    int k = (int)(((u64)r.x * (u64)cnt) >> 32);
-    if (cnt == 1) return fc + first;
-    for (int i = 0; i < nc; ++i) {
-        size_t c = base + fc + i;
-        double key = E.nQ[c] + (E.nP[c] * sq) / (double)(1 + E.nN[c]);
-        if (key == best) { if (k == 0) return fc + i; --k; }
+    double best = grp_max(fmax(fmax(key[0], key[1]), fmax(key[2], key[3])));
+    u32 mask[4];
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mask[r] = grp_ballot(key[r] == best); cnt += __popc(mask[r]); }
+    int k = 0;
+    if (E.tie_mode == AZ_TIE_RANDOM) {
+        Philox4 rr = az_philox(E.seed, E.game_id[g], (u32)ply, (u32)sim, AZ_P_TIE_SELECT, (u32)depth);
+        k = (int)(((u64)rr.x * (u64)cnt) >> 32);
     }
-    return fc + first;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int pc = __popc(mask[r]);
+        if (k < pc) return fc + r * LPG + kth_set_bit(mask[r], k);
+        k -= pc;
+    }
+    return fc;
 }
 
 AZ_D double log_gamma_draw(const EngDev &E, u32 gid, int ply, int sim, double alpha, u32 j) {
@@ -157,49 +226,67 @@ AZ_D double log_gamma_draw(const EngDev &E, u32 gid, int ply, int sim, double al
     return az_det_log(g) + az_det_log(ub) / alpha;
 }
 
-// mcts.py:235-240 : P <- (1-eps) P + eps eta over the root's children
-AZ_D void apply_root_noise(const EngDev &E, int g, int root, const BB &rb, int ply, int sim) {
-    size_t base = (size_t)g * E.C;
-    int fc = E.nfirst[base + root], k = E.nnch[base + root];
-    double eta[AZ_MAX_ACTIONS];
+AZ_D double sel4(const double (&v)[4], int r) { return r == 0 ? v[0] : (r == 1 ? v[1] : (r == 2 ? v[2] : v[3])); }
+
+// mcts.py:235-240 : P <- (1-eps) P + eps eta over the root's children, one lane per child
+AZ_D void apply_root_noise_grp(const EngDev &E, int g, Node *pool, int root, const Node &rn, const BB &rb, int ply, int sim, int sub) {
+    const int fc = rn.first, k = rn.nch;
+    double eta[4];
+    Node ch[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { int i = r * LPG + sub; ch[r] = load_node(pool + fc + (i < k ? i : 0)); }
     if (E.noise_mode == AZ_NOISE_HASH) {
-        u64 h = az_board_hash(E.gd, rb), tot = 0;
-        for (int i = 0; i < k; ++i) {
-            u64 w = 1 + (az_splitmix64(h + (u64)(E.nact[base + fc + i] + 1) * 0xBF58476D1CE4E5B9ULL) >> 54);
-            eta[i] = (double)w;
-            tot += w;
+        u64 h = az_board_hash(E.gd, rb), w[4], tot = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int i = r * LPG + sub;
+            w[r] = i < k ? 1 + (az_splitmix64(h + (u64)(ch[r].act + 1) * 0xBF58476D1CE4E5B9ULL) >> 54) : 0;
+            tot += w[r];
         }
-        for (int i = 0; i < k; ++i) eta[i] = eta[i] / (double)tot;
+        tot = grp_sum_u64(tot);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) eta[r] = (double)w[r] / (double)tot;
     } else {
-        double m = -__builtin_inf(), s = 0.0;
-        for (int i = 0; i < k; ++i) {
-            eta[i] = log_gamma_draw(E, E.game_id[g], ply, sim, E.alpha, (u32)i);
-            if (eta[i] > m) m = eta[i];
+        double lg[4], m = -__builtin_inf();
+        const u32 gid = E.game_id[g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int i = r * LPG + sub;
+            lg[r] = i < k ? log_gamma_draw(E, gid, ply, sim, E.alpha, (u32)i) : -__builtin_inf();
+            m = fmax(m, lg[r]);
         }
-        for (int i = 0; i < k; ++i) { eta[i] = az_det_exp(eta[i] - m); s += eta[i]; }
-        for (int i = 0; i < k; ++i) eta[i] = eta[i] / s;
+        m = grp_max(m);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) eta[r] = (r * LPG + sub) < k ? az_det_exp(lg[r] - m) : 0.0;
+        double s = 0.0;  // sequential sum in ascending child order, as in the CPU restatement
+        for (int i = 0; i < k; ++i) s += __shfl(sel4(eta, i >> 4), i & 15, LPG);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) eta[r] = eta[r] / s;
     }
-    for (int i = 0; i < k; ++i) {
-        size_t c = base + fc + i;
-        double P = E.nP[c];
-        double keep = (E.nflags[c] & F_PF32) ? (double)((float)(1.0 - E.eps) * (float)P) : (1.0 - E.eps) * P;
-        E.nP[c] = keep + E.eps * eta[i];
-        E.nflags[c] &= (uint8_t)~F_PF32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int i = r * LPG + sub;
+        if (i < k) {
+            double P = ch[r].P;
+            double keep = (ch[r].flags & F_PF32) ? (double)((float)(1.0 - E.eps) * (float)P) : (1.0 - E.eps) * P;
+            pool[fc + i].P = keep + E.eps * eta[r];
+            pool[fc + i].flags = ch[r].flags & (uint8_t)~F_PF32;
+        }
     }
-    E.nflags[base + root] |= F_NOISED;
+    if (sub == 0) pool[root].flags = rn.flags | F_NOISED;
 }
 
-AZ_D void back_propagate(const EngDev &E, int g, int node, int player_to_play, double outcome) {  // mcts.py:197-223
-    size_t base = (size_t)g * E.C;
+AZ_D void back_propagate_grp(Node *pool, int node, int player_to_play, double outcome, int sub) {  // mcts.py:197-223
     double reward;
     if (fabs(outcome) < 1e-4) reward = 0.0;
     else reward = ((double)player_to_play * outcome > 0.0) ? -fabs(outcome) : fabs(outcome);
     while (node >= 0) {
-        size_t i = base + node;
-        int n = E.nN[i];
-        E.nQ[i] = ((double)n * E.nQ[i] + reward) / (double)(n + 1);
-        E.nN[i] = n + 1;
-        node = E.nparent[i];
+        Node n = load_node(pool + node);  // same address in all 16 lanes: one broadcast transaction
+        if (sub == 0) {
+            pool[node].Q = ((double)n.N * n.Q + reward) / (double)(n.N + 1);
+            pool[node].N = n.N + 1;
+        }
+        node = n.parent;
         reward = (reward == 0.0) ? 0.0 : -reward;
     }
 }
@@ -210,11 +297,11 @@ AZ_D void reset_slot(const EngDev &E, int g, u32 game_id) {
     E.root_p1[g] = b.p1; E.root_m1[g] = b.m1; E.root_player[g] = (int8_t)b.player;
     E.root[g] = 0; E.n_nodes[g] = 1; E.ply[g] = 0; E.game_id[g] = game_id; E.active[g] = 1;
     E.leaf_status[g] = LS_NONE;
-    init_node(E, (size_t)g * E.C, 0, -1, 0.0, 0);
+    store_node(E.nodes + (size_t)g * E.C, fresh_node(0, -1, 0.0, 0));
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernels (one thread per slot)
+// kernels
 // ---------------------------------------------------------------------------------------------
 __global__ void k_reset_all(EngDev E, u32 first_id, int n_games) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -231,94 +318,105 @@ __global__ void k_reset_all(EngDev E, u32 first_id, int n_games) {
 }
 
 // mcts.py:231-233 : a root without priors is evaluated first (value discarded)
-__global__ void k_root_prep(EngDev E) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_root_prep(EngDev E) {
+    const int g = blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
     if (g >= E.G) return;
     uint8_t fresh = 0;
     if (E.active[g]) {
-        size_t r = (size_t)g * E.C + E.root[g];
-        if (!(E.nflags[r] & (F_EVALUATED | F_TERMINAL))) {
+        uint8_t f = E.nodes[(size_t)g * E.C + E.root[g]].flags;
+        if (!(f & (F_EVALUATED | F_TERMINAL))) {
             BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
-            write_nn_input(E, g, b);
+            write_nn_input_grp(E, g, b, sub);
             fresh = 1;
         }
     }
-    E.root_fresh[g] = fresh;
+    if (sub == 0) E.root_fresh[g] = fresh;
 }
 
-__global__ void k_root_init(EngDev E) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_root_init(EngDev E) {
+    const int g = blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
     if (g >= E.G || !E.root_fresh[g]) return;
     BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
-    create_children(E, g, E.root[g], b, E.probs + (size_t)g * E.A);
-    atomicAdd(&E.ctr[CTR_NET_EVALS], 1ULL);
+    create_children_grp(E, g, E.root[g], b, E.probs + (size_t)g * E.A, sub);
+    if (sub == 0) atomicAdd(&E.ctr[CTR_NET_EVALS], 1ULL);
 }
 
-// select_node (mcts.py:127-171) up to the point where the leaf needs its evaluation
-__global__ void k_select(EngDev E, int sim) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
+// One lock-step of the search for every slot:
+//   BACKUP : nn_evaluation bookkeeping (mcts.py:188-191) + back_propagate (mcts.py:197-223) of the
+//            leaf selected in the previous step, whose policy/value the network has just produced
+//   SELECT : root noise (mcts.py:235-240) + select_node (mcts.py:127-171) of simulation `sim`,
+//            writing the next leaf's canonical board into the network's input batch
+template <bool BACKUP, bool SELECT>
+__global__ __launch_bounds__(256) void k_step(EngDev E, int sim) {
+    const int g = blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
     if (g >= E.G) return;
-    if (!E.active[g]) { E.leaf_status[g] = LS_NONE; return; }
-    size_t base = (size_t)g * E.C;
-    int ply = E.ply[g];
+    Node *pool = E.nodes + (size_t)g * E.C;
+    if (BACKUP) {
+        int st = E.leaf_status[g];
+        if (st != LS_NONE) {
+            int node = E.leaf[g];
+            BB b = {E.leaf_p1[g], E.leaf_m1[g], E.leaf_player[g]};
+            double outcome;
+            bool ok = true;
+            if (st == LS_EVAL) {
+                ok = create_children_grp(E, g, node, b, E.probs + (size_t)g * E.A, sub);
+                outcome = (double)b.player * (double)E.value[g];  // base.py:366
+                if (sub == 0) { if (ok) atomicAdd(&E.ctr[CTR_NET_EVALS], 1ULL); else E.active[g] = 0; }
+            } else {
+                outcome = (double)E.leaf_winner[g];
+            }
+            if (ok) back_propagate_grp(pool, node, b.player, outcome, sub);
+            if (sub == 0) E.leaf_status[g] = LS_NONE;
+        }
+        // the group's own stores (other lanes) must be visible to the loads below
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    if (!SELECT) return;
+    if (!E.active[g]) { if (sub == 0) E.leaf_status[g] = LS_NONE; return; }
+    const int ply = E.ply[g];
     BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
     int node = E.root[g];
-    if (E.noise_mode != AZ_NOISE_OFF && E.alpha >= 0.0 && E.eps >= 0.0) {  // mcts.py:235-240
-        uint8_t f = E.nflags[base + node];
-        if ((f & F_EXPANDED) && !(f & F_NOISED)) apply_root_noise(E, g, node, b, ply, sim);
+    Node cur = load_node(pool + node);
+    if (E.noise_mode != AZ_NOISE_OFF && E.alpha >= 0.0 && E.eps >= 0.0 && (cur.flags & F_EXPANDED) && !(cur.flags & F_NOISED)) {
+        apply_root_noise_grp(E, g, pool, node, cur, b, ply, sim, sub);
+        cur.flags |= F_NOISED;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
     int depth = 0;
+    bool bad = false;
     for (;;) {
-        uint8_t f = E.nflags[base + node];
-        if (f & F_EXPANDED) {
-            int c = pick_child(E, g, node, ply, sim, depth++);
-            az_play(E.gd, b, E.nact[base + c]);
+        if (cur.flags & F_EXPANDED) {
+            int c = pick_child_grp(E, g, pool, cur, ply, sim, depth++, sub);
             node = c;
-            if (E.nN[base + c] == 0) break;  // mcts.py:143-144
+            cur = load_node(pool + c);
+            az_play(E.gd, b, cur.act);
+            if (cur.N == 0) break;  // mcts.py:143-144
             continue;
         }
-        if (f & F_TERMINAL) break;  // mcts.py:146-147
-        if (!(f & F_EVALUATED)) { atomicOr(E.err, ERR_INTERNAL); E.leaf_status[g] = LS_NONE; return; }
-        E.nflags[base + node] = f | F_EXPANDED;  // mcts.py:151-160 : children become visible now
-        int c = pick_child(E, g, node, ply, sim, depth);
-        az_play(E.gd, b, E.nact[base + c]);
+        if (cur.flags & F_TERMINAL) break;  // mcts.py:146-147
+        if (!(cur.flags & F_EVALUATED)) { bad = true; break; }
+        cur.flags |= F_EXPANDED;  // mcts.py:151-160 : children become visible now
+        if (sub == 0) pool[node].flags = cur.flags;
+        int c = pick_child_grp(E, g, pool, cur, ply, sim, depth, sub);
         node = c;
+        cur = load_node(pool + c);
+        az_play(E.gd, b, cur.act);
         break;
     }
-    E.leaf[g] = node; E.leaf_p1[g] = b.p1; E.leaf_m1[g] = b.m1; E.leaf_player[g] = (int8_t)b.player;
-    uint8_t lf = E.nflags[base + node];
-    if (lf & F_TERMINAL) {
-        E.leaf_status[g] = LS_TERM; E.leaf_winner[g] = E.nwin[base + node];
+    if (bad) { if (sub == 0) { atomicOr(E.err, ERR_INTERNAL); E.leaf_status[g] = LS_NONE; } return; }
+    int status, w = 0;
+    if (cur.flags & F_TERMINAL) { status = LS_TERM; w = cur.win; }
+    else if (az_status(E.gd, b, &w)) {  // mcts.py:185-186
+        status = LS_TERM;
+        if (sub == 0) { pool[node].flags = cur.flags | F_TERMINAL; pool[node].win = (int8_t)w; }
     } else {
-        int w = 0;
-        if (az_status(E.gd, b, &w)) {  // mcts.py:185-186
-            E.nflags[base + node] = lf | F_TERMINAL; E.nwin[base + node] = (int8_t)w;
-            E.leaf_status[g] = LS_TERM; E.leaf_winner[g] = (int8_t)w;
-        } else {
-            write_nn_input(E, g, b);
-            E.leaf_status[g] = LS_EVAL;
-        }
+        status = LS_EVAL;
+        write_nn_input_grp(E, g, b, sub);
     }
-}
-
-// nn_evaluation bookkeeping (mcts.py:188-191) + back_propagate (mcts.py:197-223)
-__global__ void k_backup(EngDev E) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= E.G) return;
-    int st = E.leaf_status[g];
-    if (st == LS_NONE) return;
-    int node = E.leaf[g];
-    BB b = {E.leaf_p1[g], E.leaf_m1[g], E.leaf_player[g]};
-    double outcome;
-    if (st == LS_EVAL) {
-        if (create_children(E, g, node, b, E.probs + (size_t)g * E.A) != 0) { E.active[g] = 0; return; }
-        outcome = (double)b.player * (double)E.value[g];  // base.py:366
-        atomicAdd(&E.ctr[CTR_NET_EVALS], 1ULL);
-    } else {
-        outcome = (double)E.leaf_winner[g];
+    if (sub == 0) {
+        E.leaf[g] = node; E.leaf_p1[g] = b.p1; E.leaf_m1[g] = b.m1; E.leaf_player[g] = (int8_t)b.player;
+        E.leaf_status[g] = (int8_t)status; E.leaf_winner[g] = (int8_t)w;
     }
-    back_propagate(E, g, node, b.player, outcome);
-    E.leaf_status[g] = LS_NONE;
 }
 
 AZ_D double linear_temp(int step, int tmax, int tmin) {  // schedulers.py:33-40
@@ -328,17 +426,18 @@ AZ_D double linear_temp(int step, int tmax, int tmin) {  // schedulers.py:33-40
 }
 
 // get_action_probs (mcts.py:95-116) + move choice (players.py:184-189) + Sample (trainer.py:244-250)
-// + play_move / change_root (trainer.py:253-256) + end-of-game bookkeeping (trainer.py:262-268)
+// + play_move / change_root (trainer.py:253-256) + end-of-game bookkeeping (trainer.py:262-268).
+// Once per ply: one thread per slot.
 __global__ void k_move(EngDev E) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.G || !E.active[g]) return;
     const GameDesc &gd = E.gd;
-    size_t base = (size_t)g * E.C;
+    Node *pool = E.nodes + (size_t)g * E.C;
     int ply = E.ply[g], root = E.root[g];
     u32 gid = E.game_id[g];
     BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
-    int fc = E.nfirst[base + root], nc = E.nnch[base + root];
-    if (nc == 0 || !(E.nflags[base + root] & F_EXPANDED)) { atomicOr(E.err, ERR_INTERNAL); E.active[g] = 0; return; }
+    int fc = pool[root].first, nc = pool[root].nch;
+    if (nc == 0 || !(pool[root].flags & F_EXPANDED)) { atomicOr(E.err, ERR_INTERNAL); E.active[g] = 0; return; }
     double temp = linear_temp(ply, E.tmax, E.tmin);
 
     long long si = (long long)atomicAdd(&E.ctr[CTR_SAMPLES], 1ULL);
@@ -353,7 +452,7 @@ __global__ void k_move(EngDev E) {
     if (temp == 0.0) {  // fair_max by N
         int best = -1, cnt = 0, first = 0;
         for (int i = 0; i < nc; ++i) {
-            int n = E.nN[base + fc + i];
+            int n = pool[fc + i].N;
             if (n > best) { best = n; cnt = 1; first = i; } else if (n == best) cnt++;
         }
         int pick = first;
@@ -361,14 +460,14 @@ __global__ void k_move(EngDev E) {
             Philox4 r = az_philox(E.seed, gid, (u32)ply, 0xFFFFu, AZ_P_TIE_MOVE, 0);
             int k = (int)(((u64)r.x * (u64)cnt) >> 32);
             for (int i = 0; i < nc; ++i)
-                if (E.nN[base + fc + i] == best) { if (k == 0) { pick = i; break; } --k; }
+                if (pool[fc + i].N == best) { if (k == 0) { pick = i; break; } --k; }
         }
         chosen = fc + pick;
-        if (si >= 0) pi[E.nact[base + chosen]] = 1.0f;
+        if (si >= 0) pi[pool[chosen].act] = 1.0f;
     } else {
         double sum = 0.0;
         for (int i = 0; i < nc; ++i) {
-            double n = (double)E.nN[base + fc + i];
+            double n = (double)pool[fc + i].N;
             sum += (temp == 1.0) ? n : pow(n, 1.0 / temp);
         }
         double u = 2.0, cum = 0.0;
@@ -378,18 +477,18 @@ __global__ void k_move(EngDev E) {
         }
         int last = 0; bool found = false;
         for (int i = 0; i < nc; ++i) {
-            double n = (double)E.nN[base + fc + i];
+            double n = (double)pool[fc + i].N;
             double p = ((temp == 1.0) ? n : pow(n, 1.0 / temp)) / sum;
-            if (si >= 0) pi[E.nact[base + fc + i]] = (float)p;
+            if (si >= 0) pi[pool[fc + i].act] = (float)p;
             if (p > 0.0) last = i;
             cum += p;
             if (!found && u < cum) { chosen = fc + i; found = true; }
         }
         if (!found) chosen = fc + (nc == 1 ? 0 : last);
     }
-    int action = E.nact[base + chosen];
+    int action = pool[chosen].act;
     if (si >= 0) {
-        for (int i = 0; i < nc; ++i) vis[E.nact[base + fc + i]] = E.nN[base + fc + i];
+        for (int i = 0; i < nc; ++i) vis[pool[fc + i].act] = pool[fc + i].N;
         int8_t *st = E.o_state + (size_t)si * gd.cells;
         for (int r = 0; r < gd.H; ++r)
             for (int c = 0; c < gd.W; ++c) st[r * gd.W + c] = (int8_t)(b.player * az_cell_value(b, r, c));
@@ -400,7 +499,7 @@ __global__ void k_move(EngDev E) {
     az_play(gd, b, action);
     E.root_p1[g] = b.p1; E.root_m1[g] = b.m1; E.root_player[g] = (int8_t)b.player;
     E.root[g] = chosen;
-    E.nparent[base + chosen] = -1;  // mcts.py:121-123
+    pool[chosen].parent = -1;  // mcts.py:121-123
     E.ply[g] = ply + 1;
     atomicAdd(&E.ctr[CTR_PLIES], 1ULL);
     int w = 0;
@@ -512,7 +611,7 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
     A_(root_p1, G); A_(root_m1, G); A_(root_player, G); A_(root, G); A_(n_nodes, G); A_(ply, G); A_(game_id, G);
     A_(active, G); A_(root_fresh, G); A_(leaf, G); A_(leaf_p1, G); A_(leaf_m1, G); A_(leaf_player, G);
     A_(leaf_status, G); A_(leaf_winner, G);
-    A_(nN, NC); A_(nQ, NC); A_(nP, NC); A_(nparent, NC); A_(nfirst, NC); A_(nnch, NC); A_(nact, NC); A_(nflags, NC); A_(nwin, NC);
+    A_(nodes, NC);
     A_(nn_in, G * gd.cells); A_(probs, G * gd.A); A_(value, G);
     A_(samp_idx, G * (size_t)d.max_plies);
     A_(o_state, S * gd.cells); A_(o_pi, S * gd.A); A_(o_z, S); A_(o_meta, S * 4); A_(o_visits, S * gd.A);
@@ -545,15 +644,16 @@ static int forward(az_engine *e) {
 
 static int do_search(az_engine *e, int n_sim) {
     EngDev &d = e->d;
-    dim3 gr = grid_for(d.G, TB), bl(TB);
-    hipLaunchKernelGGL(k_root_prep, gr, bl, 0, e->stream, d);
+    dim3 gg((unsigned)((d.G + GPB - 1) / GPB)), gb(256);
+    hipLaunchKernelGGL(k_root_prep, gg, gb, 0, e->stream, d);
     AZ_TRY(forward(e));
-    hipLaunchKernelGGL(k_root_init, gr, bl, 0, e->stream, d);
+    hipLaunchKernelGGL(k_root_init, gg, gb, 0, e->stream, d);
     for (int s = 0; s < n_sim; ++s) {
-        hipLaunchKernelGGL(k_select, gr, bl, 0, e->stream, d, s);
+        if (s == 0) hipLaunchKernelGGL((k_step<false, true>), gg, gb, 0, e->stream, d, s);
+        else hipLaunchKernelGGL((k_step<true, true>), gg, gb, 0, e->stream, d, s);
         AZ_TRY(forward(e));
-        hipLaunchKernelGGL(k_backup, gr, bl, 0, e->stream, d);
     }
+    hipLaunchKernelGGL((k_step<true, false>), gg, gb, 0, e->stream, d, n_sim);
     e->lockstep_iters += n_sim + 1;
     AZ_HIP(hipGetLastError());
     return AZ_OK;
@@ -675,23 +775,22 @@ extern "C" int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_ac
     EngDev &d = e->d;
     AZ_REQUIRE(slot >= 0 && slot < d.G, AZ_EINVAL, "slot out of range");
     AZ_HIP(hipStreamSynchronize(e->stream));
-    int root = 0, fc = 0, rn = 0;
-    uint8_t nc = 0, fl = 0;
+    int root = 0;
     size_t base = (size_t)slot * d.C;
     AZ_HIP(hipMemcpy(&root, d.root + slot, sizeof(int), hipMemcpyDeviceToHost));
-    AZ_HIP(hipMemcpy(&fc, d.nfirst + base + root, sizeof(int), hipMemcpyDeviceToHost));
-    AZ_HIP(hipMemcpy(&nc, d.nnch + base + root, 1, hipMemcpyDeviceToHost));
-    AZ_HIP(hipMemcpy(&fl, d.nflags + base + root, 1, hipMemcpyDeviceToHost));
-    AZ_HIP(hipMemcpy(&rn, d.nN + base + root, sizeof(int), hipMemcpyDeviceToHost));
-    if (root_N) *root_N = rn;
-    if (!(fl & F_EXPANDED)) nc = 0;  // children not materialised yet in the reference's tree
+    Node rn;
+    AZ_HIP(hipMemcpy(&rn, d.nodes + base + root, sizeof(Node), hipMemcpyDeviceToHost));
+    if (root_N) *root_N = rn.N;
+    int nc = (rn.flags & F_EXPANDED) ? rn.nch : 0;  // children not materialised yet in the reference's tree
     *count = nc;
     if (nc == 0) return AZ_OK;
-    std::vector<uint8_t> act(nc);
-    AZ_HIP(hipMemcpy(act.data(), d.nact + base + fc, nc, hipMemcpyDeviceToHost));
-    if (h_actions) for (int i = 0; i < nc; ++i) h_actions[i] = act[i];
-    if (h_N) AZ_HIP(hipMemcpy(h_N, d.nN + base + fc, sizeof(int) * nc, hipMemcpyDeviceToHost));
-    if (h_Q) AZ_HIP(hipMemcpy(h_Q, d.nQ + base + fc, sizeof(double) * nc, hipMemcpyDeviceToHost));
-    if (h_P) AZ_HIP(hipMemcpy(h_P, d.nP + base + fc, sizeof(double) * nc, hipMemcpyDeviceToHost));
+    std::vector<Node> ch(nc);
+    AZ_HIP(hipMemcpy(ch.data(), d.nodes + base + rn.first, sizeof(Node) * nc, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nc; ++i) {
+        if (h_actions) h_actions[i] = ch[i].act;
+        if (h_N) h_N[i] = ch[i].N;
+        if (h_Q) h_Q[i] = ch[i].Q;
+        if (h_P) h_P[i] = ch[i].P;
+    }
     return AZ_OK;
 }

@@ -58,26 +58,36 @@ AZ_D void conv_mfma(const float *in_lds, const float *__restrict__ wf, const flo
         p = p < P_OUT ? p : P_OUT - 1;
         abase[mt] = kq * IN_PS + (p / W_OUT) * IN_W + (p % W_OUT);
     }
+    const float *wl = wf + lane;
+    // weight fragments of one tap (8 k-steps x 2 oc tiles) live in registers; the next tap's 16
+    // coalesced dword loads are issued before this tap's MFMAs so L2 latency hides under them
+    float bcur[16], bnxt[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bcur[i] = wl[i * 64];
     const float bv0 = bias[m_lane], bv1 = bias[16 + m_lane];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         acc[mt][0] = (f32x4){bv0, bv0, bv0, bv0};
         acc[mt][1] = (f32x4){bv1, bv1, bv1, bv1};
     }
-    const float *wl = wf + lane;
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int toff = (tap / 3) * IN_W + (tap % 3);
+        if (tap < 8) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bnxt[i] = wl[((tap + 1) * 16 + i) * 64];
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float b0 = wl[((tap * 8 + j) * 2 + 0) * 64];
-            const float b1 = wl[((tap * 8 + j) * 2 + 1) * 64];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const float a = in_lds[abase[mt] + toff + 4 * j * IN_PS];
-                acc[mt][0] = MFMA(a, b0, acc[mt][0]);
-                acc[mt][1] = MFMA(a, b1, acc[mt][1]);
+                acc[mt][0] = MFMA(a, bcur[2 * j + 0], acc[mt][0]);
+                acc[mt][1] = MFMA(a, bcur[2 * j + 1], acc[mt][1]);
             }
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bcur[i] = bnxt[i];
     }
 }
 
@@ -169,16 +179,20 @@ __global__ __launch_bounds__(256) void k_trunk(const float *__restrict__ in, int
     }
 }
 
-// C[M][N] = act(A[M][K] * Bw[K][N] + bias[N]);  K % 16 == 0, N % BN == 0
+// C[M][N] = act(A[M][K] * Bw[K][N] + bias[N]);  K % 32 == 0, N % BN == 0.
+// LDS double buffer, BK = 32, one barrier per K tile; the next tile's global loads are issued
+// before the current tile's 8 MFMA k-steps and written to the other buffer after them.
 template <int BM, int BN, int WM, int WN, bool RELU>
 __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const float *__restrict__ Bw,
                                               const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K) {
-    constexpr int BK = 16, WAVES_N = BN / WN, TM = WM / 16, TN = WN / 16;
+    constexpr int BK = 32, WAVES_N = BN / WN, TM = WM / 16, TN = WN / 16;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
-    constexpr int A_LD = BM / 64, B_LD = BN / 64 > 0 ? BN / 64 : 1;
-    constexpr int BNP = BN + 16;
-    __shared__ float As[BM][BK + 1];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][BNP];
+    constexpr int ASTR = BK + 2;   // (2m + kq) mod 32 : conflict-free A-fragment reads
+    constexpr int BSTR = BN + 16;  // (16 kq + n) mod 32 : conflict-free B-fragment reads
+    constexpr int A_LD = BM * BK / 4 / 256, B_LD = (BK * BN / 4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float *As = gsm;                    // [2][BM][ASTR]
+    float *Bs = gsm + 2 * BM * ASTR;    // [2][BK][BSTR]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
     const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
@@ -189,54 +203,76 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = (f32x4){bv, bv, bv, bv};
     }
-    float4 ra[A_LD], rb[B_LD];
-    auto issue = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            int idx = tid + i * 256, row = idx >> 2, q = idx & 3;
-            int gr = bm0 + row;
-            ra[i] = gr < M ? *reinterpret_cast<const float4 *>(A + (size_t)gr * K + k0 + 4 * q) : make_float4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            int idx = tid + i * 256;
-            if (BN >= 64 || idx < 4 * BN) {
-                int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-                rb[i] = *reinterpret_cast<const float4 *>(Bw + (size_t)(k0 + kr) * N + bn0 + 4 * c4);
-            }
-        }
-    };
-    issue(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            int idx = tid + i * 256, row = idx >> 2, q = idx & 3;
-            As[row][4 * q + 0] = ra[i].x; As[row][4 * q + 1] = ra[i].y; As[row][4 * q + 2] = ra[i].z; As[row][4 * q + 3] = ra[i].w;
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            int idx = tid + i * 256;
-            if (BN >= 64 || idx < 4 * BN) {
-                int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-                *reinterpret_cast<float4 *>(&Bs[kr][4 * c4]) = rb[i];
-            }
-        }
-        __syncthreads();
-        if (k0 + BK < K) issue(k0 + BK);
+    // staging registers as named scalars (an indexed array here ends up in scratch)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0, 0, 0, 0);
+#define LD_A(i, r, k0)                                                                    \
+    if constexpr ((i) < A_LD) {                                                           \
+        int idx = tid + (i) * 256, row = idx / (BK / 4), q = idx % (BK / 4);              \
+        int gr = bm0 + row;                                                               \
+        gr = gr < M ? gr : M - 1;                                                         \
+        r = *reinterpret_cast<const float4 *>(A + (size_t)gr * K + (k0) + 4 * q);         \
+    }
+#define LD_B(i, r, k0)                                                                    \
+    if constexpr ((i) < B_LD) {                                                           \
+        int idx = tid + (i) * 256;                                                        \
+        if (BK * BN / 4 >= 256 * ((i) + 1) || idx < BK * BN / 4) {                        \
+            int kr = idx / (BN / 4), c4 = idx % (BN / 4);                                 \
+            r = *reinterpret_cast<const float4 *>(Bw + (size_t)((k0) + kr) * N + bn0 + 4 * c4); \
+        }                                                                                 \
+    }
+#define ST_A(i, r, as)                                                                    \
+    if constexpr ((i) < A_LD) {                                                           \
+        int idx = tid + (i) * 256, row = idx / (BK / 4), q = idx % (BK / 4);              \
+        float *d = (as) + row * ASTR + 4 * q;                                             \
+        *reinterpret_cast<float2 *>(d) = make_float2(r.x, r.y);                           \
+        *reinterpret_cast<float2 *>(d + 2) = make_float2(r.z, r.w);                       \
+    }
+#define ST_B(i, r, bs)                                                                    \
+    if constexpr ((i) < B_LD) {                                                           \
+        int idx = tid + (i) * 256;                                                        \
+        if (BK * BN / 4 >= 256 * ((i) + 1) || idx < BK * BN / 4) {                        \
+            int kr = idx / (BN / 4), c4 = idx % (BN / 4);                                 \
+            *reinterpret_cast<float4 *>((bs) + kr * BSTR + 4 * c4) = r;                   \
+        }                                                                                 \
+    }
+#define GEMM_ISSUE(k0) { LD_A(0, ra0, k0) LD_A(1, ra1, k0) LD_A(2, ra2, k0) LD_A(3, ra3, k0) LD_B(0, rb0, k0) LD_B(1, rb1, k0) LD_B(2, rb2, k0) LD_B(3, rb3, k0) }
+#define GEMM_STORE(buf)                                                                   \
+    {                                                                                     \
+        float *as_ = As + (buf) * BM * ASTR, *bs_ = Bs + (buf) * BK * BSTR;               \
+        ST_A(0, ra0, as_) ST_A(1, ra1, as_) ST_A(2, ra2, as_) ST_A(3, ra3, as_)           \
+        ST_B(0, rb0, bs_) ST_B(1, rb1, bs_) ST_B(2, rb2, bs_) ST_B(3, rb3, bs_)           \
+    }
+    static_assert(A_LD <= 4 && B_LD <= 4, "staging register budget");
+    GEMM_ISSUE(0)
+    GEMM_STORE(0)
+    __syncthreads();
+    const int T = K / BK;
+    for (int t = 0; t < T; ++t) {
+        const bool more = t + 1 < T;
+        if (more) GEMM_ISSUE((t + 1) * BK)
+        const float *as = As + (t & 1) * BM * ASTR, *bs = Bs + (t & 1) * BK * BSTR;
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             float af[TM], bf[TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) af[tm] = As[wm0 + tm * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+            for (int tm = 0; tm < TM; ++tm) af[tm] = as[(wm0 + tm * 16 + (lane & 15)) * ASTR + ks * 4 + (lane >> 4)];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bf[tn] = Bs[ks * 4 + (lane >> 4)][wn0 + tn * 16 + (lane & 15)];
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = bs[(ks * 4 + (lane >> 4)) * BSTR + wn0 + tn * 16 + (lane & 15)];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA(af[tm], bf[tn], acc[tm][tn]);
         }
+        if (more) GEMM_STORE((t + 1) & 1)
         __syncthreads();
     }
+#undef GEMM_ISSUE
+#undef GEMM_STORE
+#undef LD_A
+#undef LD_B
+#undef ST_A
+#undef ST_B
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -251,6 +287,9 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const
             }
 }
 
+template <int BM, int BN>
+constexpr int gemm_lds_bytes() { return 4 * (2 * BM * (32 + 2) + 2 * 32 * (BN + 16)); }
+
 // policy + value heads (othello.py:379-382, base.py:355): logits = h2 * Wh + bh with
 // Wh = [fc_probs | fc_value | 0-pad] of width NH = 16*NT; then softmax over the first A columns
 // and tanh of column A.  64 rows per block (4 waves x 16 rows).
@@ -258,21 +297,37 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_heads(const float *__restrict__ X, const float *__restrict__ Wh,
                                                const float *__restrict__ bh, int M, int K, int A,
                                                float *__restrict__ probs, float *__restrict__ value) {
-    constexpr int NH = NT * 16;
+    constexpr int NH = NT * 16, KC = 128, XSTR = KC + 2;
+    __shared__ __attribute__((aligned(16))) float Xs[64][XSTR];
     __shared__ float Ls[64][NH + 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row0 = blockIdx.x * 64 + wave * 16;
+    const int brow0 = blockIdx.x * 64;
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { float bv = bh[nt * 16 + (lane & 15)]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
-    int arow = row0 + (lane & 15);
-    arow = arow < M ? arow : M - 1;
-    const float *ap = X + (size_t)arow * K + (lane >> 4);
     const float *bp = Wh + (size_t)(lane >> 4) * NH + (lane & 15);
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        float a = ap[k0];
+    const float *xa = &Xs[wave * 16 + (lane & 15)][lane >> 4];
+    for (int kc = 0; kc < K; kc += KC) {
+        const int kw = K - kc < KC ? K - kc : KC;  // chunk width (K is a multiple of 4)
+        __syncthreads();
+        for (int idx = tid; idx < 64 * (KC / 4); idx += 256) {
+            int row = idx / (KC / 4), q = idx % (KC / 4);
+            int gr = brow0 + row;
+            gr = gr < M ? gr : M - 1;
+            if (4 * q < kw) {
+                float4 v = *reinterpret_cast<const float4 *>(X + (size_t)gr * K + kc + 4 * q);
+                float *d = &Xs[row][4 * q];
+                *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2 *>(d + 2) = make_float2(v.z, v.w);
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k0 = 0; k0 < kw; k0 += 4) {
+            float a = xa[k0];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA(a, bp[(size_t)k0 * NH + nt * 16], acc[nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA(a, bp[(size_t)(kc + k0) * NH + nt * 16], acc[nt]);
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -280,7 +335,7 @@ __global__ __launch_bounds__(256) void k_heads(const float *__restrict__ X, cons
         for (int r = 0; r < 4; ++r) Ls[wave * 16 + (lane >> 4) * 4 + r][nt * 16 + (lane & 15)] = acc[nt][r];
     __syncthreads();
     if (tid < 64) {
-        int row = blockIdx.x * 64 + tid;
+        int row = brow0 + tid;
         if (row < M) {
             float *l = Ls[tid];
             float m = l[0];
@@ -517,22 +572,29 @@ static int launch_trunk(az_net *n, const float *in, int B, hipStream_t st) {
     return AZ_OK;
 }
 
-static int launch_gemm(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, hipStream_t st) {
-    AZ_REQUIRE(K % 16 == 0, AZ_EINVAL, "GEMM K=%d is not a multiple of 16", K);
-#define GO(BM, BN, WM, WN)                                                                                     \
-    do {                                                                                                       \
-        dim3 grid(N / BN, (M + BM - 1) / BM);                                                                  \
-        if (relu) hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, A, Bw, bias, C, M, N, K);  \
-        else hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, A, Bw, bias, C, M, N, K);     \
-        return AZ_OK;                                                                                          \
-    } while (0)
-    if (N % 128 == 0) {
-        if ((long long)((M + 127) / 128) * (N / 128) >= 256) GO(128, 128, 64, 64);
-        GO(64, 128, 32, 64);
+template <int BM, int BN, int WM, int WN>
+static int gemm_go(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, hipStream_t st) {
+    constexpr int lds = gemm_lds_bytes<BM, BN>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
     }
-    if (N % 64 == 0) GO(128, 64, 32, 64);
-    if (N % 32 == 0) GO(128, 32, 32, 32);
-#undef GO
+    dim3 grid(N / BN, (M + BM - 1) / BM);
+    if (relu) hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K);
+    else hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K);
+    return AZ_OK;
+}
+
+static int launch_gemm(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, hipStream_t st) {
+    AZ_REQUIRE(K % 32 == 0, AZ_EINVAL, "GEMM K=%d is not a multiple of 32", K);
+    if (N % 128 == 0) {
+        if ((long long)((M + 127) / 128) * (N / 128) >= 256) return gemm_go<128, 128, 64, 64>(A, Bw, bias, C, M, N, K, relu, st);
+        return gemm_go<64, 128, 32, 64>(A, Bw, bias, C, M, N, K, relu, st);
+    }
+    if (N % 64 == 0) return gemm_go<128, 64, 32, 64>(A, Bw, bias, C, M, N, K, relu, st);
+    if (N % 32 == 0) return gemm_go<128, 32, 32, 32>(A, Bw, bias, C, M, N, K, relu, st);
     az_set_error("GEMM N=%d is not a multiple of 32", N);
     return AZ_EINVAL;
 }
