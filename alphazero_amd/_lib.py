@@ -34,7 +34,8 @@ class EngineStats(C.Structure):
 # every symbol include/az_amd.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "az_last_error", "az_version", "az_board_legal_batch", "az_board_play_batch", "az_board_status_batch",
-    "az_net_create", "az_net_destroy", "az_net_set_tensor", "az_net_commit", "az_net_forward", "az_net_action_size",
+    "az_net_create", "az_net_destroy", "az_net_set_tensor", "az_net_commit", "az_net_forward", "az_net_forward_dyn",
+    "az_net_action_size",
     "az_net_flops_per_board", "az_net_time_stage", "az_engine_create", "az_engine_destroy", "az_engine_run",
     "az_engine_get_stats", "az_engine_samples", "az_engine_set_roots", "az_engine_search", "az_engine_advance",
     "az_engine_root_children",
@@ -60,6 +61,7 @@ def lib():
     L.az_net_set_tensor.argtypes = [vp, C.c_char_p, vp, i64]
     L.az_net_commit.argtypes = [vp, vp]
     L.az_net_forward.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.az_net_forward_dyn.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
     L.az_net_action_size.argtypes = [vp]
     L.az_net_flops_per_board.argtypes = [vp]
     L.az_net_flops_per_board.restype = i64

@@ -68,6 +68,8 @@ struct EngDev {
     int *leaf; u64 *leaf_p1, *leaf_m1; int8_t *leaf_player, *leaf_status, *leaf_winner;
     Node *nodes;
     float *nn_in, *probs, *value;
+    int *row_of_slot;  // network batch row holding the slot's pending leaf (leaves are compacted)
+    int *batch_cnt;    // [3] rows filled: two alternating lock-step counters + the root-prior pass
     int *samp_idx;
     int8_t *o_state; float *o_pi; int8_t *o_z; int *o_meta, *o_visits;
     unsigned long long *ctr;
@@ -121,6 +123,13 @@ AZ_D int kth_set_bit(u32 mask, int k) {
     return __ffs((int)mask) - 1;
 }
 
+// next free row of the network batch for this group (lane 0 draws it, the group gets it by shuffle)
+AZ_D int alloc_row_grp(int *counter, int sub) {
+    int row = 0;
+    if (sub == 0) row = atomicAdd(counter, 1);
+    return __shfl(row, 0, LPG);
+}
+
 AZ_D void start_position(const GameDesc &gd, BB &b) {
     b.p1 = 0; b.m1 = 0; b.player = 1;
     if (gd.game == AZ_OTHELLO) {  // othello.py:102-109
@@ -131,8 +140,8 @@ AZ_D void start_position(const GameDesc &gd, BB &b) {
 }
 
 // base.py:363 : player * grid, spread over the group's lanes (coalesced row of `cells` floats)
-AZ_D void write_nn_input_grp(const EngDev &E, int g, const BB &b, int sub) {
-    float *dst = E.nn_in + (size_t)g * E.gd.cells;
+AZ_D void write_nn_input_grp(const EngDev &E, int row, const BB &b, int sub) {
+    float *dst = E.nn_in + (size_t)row * E.gd.cells;
     for (int i = sub; i < E.gd.cells; i += LPG) dst[i] = (float)(b.player * az_cell_value(b, i / E.gd.W, i % E.gd.W));
 }
 
@@ -311,6 +320,7 @@ __global__ void k_reset_all(EngDev E, u32 first_id, int n_games) {
         E.ctr[CTR_TOTAL_GAMES] = (unsigned long long)n_games;
         E.ctr[CTR_FIRST_ID] = first_id;
         *E.err = 0; *E.max_nodes = 0;
+        E.batch_cnt[0] = E.batch_cnt[1] = E.batch_cnt[2] = 0;
     }
     if (g >= E.G) return;
     if (g < n_games) reset_slot(E, g, first_id + (u32)g);
@@ -318,26 +328,30 @@ __global__ void k_reset_all(EngDev E, u32 first_id, int n_games) {
 }
 
 // mcts.py:231-233 : a root without priors is evaluated first (value discarded)
-__global__ __launch_bounds__(256) void k_root_prep(EngDev E) {
-    const int g = blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
-    if (g >= E.G) return;
+__global__ __launch_bounds__(256) void k_root_prep(EngDev E, int g0, int g1) {
+    const int g = g0 + blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
+    if (g >= g1) return;
     uint8_t fresh = 0;
     if (E.active[g]) {
         uint8_t f = E.nodes[(size_t)g * E.C + E.root[g]].flags;
         if (!(f & (F_EVALUATED | F_TERMINAL))) {
-            BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
-            write_nn_input_grp(E, g, b, sub);
             fresh = 1;
         }
+    }
+    if (fresh) {
+        BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
+        int row = alloc_row_grp(E.batch_cnt + 2, sub);
+        write_nn_input_grp(E, row, b, sub);
+        if (sub == 0) E.row_of_slot[g] = row;
     }
     if (sub == 0) E.root_fresh[g] = fresh;
 }
 
-__global__ __launch_bounds__(256) void k_root_init(EngDev E) {
-    const int g = blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
-    if (g >= E.G || !E.root_fresh[g]) return;
+__global__ __launch_bounds__(256) void k_root_init(EngDev E, int g0, int g1) {
+    const int g = g0 + blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
+    if (g >= g1 || !E.root_fresh[g]) return;
     BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
-    create_children_grp(E, g, E.root[g], b, E.probs + (size_t)g * E.A, sub);
+    create_children_grp(E, g, E.root[g], b, E.probs + (size_t)E.row_of_slot[g] * E.A, sub);
     if (sub == 0) atomicAdd(&E.ctr[CTR_NET_EVALS], 1ULL);
 }
 
@@ -347,9 +361,12 @@ __global__ __launch_bounds__(256) void k_root_init(EngDev E) {
 //   SELECT : root noise (mcts.py:235-240) + select_node (mcts.py:127-171) of simulation `sim`,
 //            writing the next leaf's canonical board into the network's input batch
 template <bool BACKUP, bool SELECT>
-__global__ __launch_bounds__(256) void k_step(EngDev E, int sim) {
-    const int g = blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
-    if (g >= E.G) return;
+__global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1) {
+    const int g = g0 + blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
+    // this step's leaves are compacted into rows [0, batch_cnt[sim & 1]); the other counter (read by the
+    // previous step's network kernels, which have completed) is cleared for the next step
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g0 == 0) { E.batch_cnt[(sim + 1) & 1] = 0; if (!SELECT) E.batch_cnt[2] = 0; }
+    if (g >= g1) return;
     Node *pool = E.nodes + (size_t)g * E.C;
     if (BACKUP) {
         int st = E.leaf_status[g];
@@ -359,8 +376,9 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim) {
             double outcome;
             bool ok = true;
             if (st == LS_EVAL) {
-                ok = create_children_grp(E, g, node, b, E.probs + (size_t)g * E.A, sub);
-                outcome = (double)b.player * (double)E.value[g];  // base.py:366
+                const int row = E.row_of_slot[g];
+                ok = create_children_grp(E, g, node, b, E.probs + (size_t)row * E.A, sub);
+                outcome = (double)b.player * (double)E.value[row];  // base.py:366
                 if (sub == 0) { if (ok) atomicAdd(&E.ctr[CTR_NET_EVALS], 1ULL); else E.active[g] = 0; }
             } else {
                 outcome = (double)E.leaf_winner[g];
@@ -411,7 +429,9 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim) {
         if (sub == 0) { pool[node].flags = cur.flags | F_TERMINAL; pool[node].win = (int8_t)w; }
     } else {
         status = LS_EVAL;
-        write_nn_input_grp(E, g, b, sub);
+        const int row = alloc_row_grp(E.batch_cnt + (sim & 1), sub);
+        write_nn_input_grp(E, row, b, sub);
+        if (sub == 0) E.row_of_slot[g] = row;
     }
     if (sub == 0) {
         E.leaf[g] = node; E.leaf_p1[g] = b.p1; E.leaf_m1[g] = b.m1; E.leaf_player[g] = (int8_t)b.player;
@@ -516,9 +536,9 @@ __global__ void k_move(EngDev E) {
 }
 
 // closed-form fake network (tests): reads the canonical board back from nn_in
-__global__ void k_fakenet(EngDev E) {
+__global__ void k_fakenet(EngDev E, const int *cnt) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= E.G) return;
+    if (g >= E.G || g >= *cnt) return;
     const float *in = E.nn_in + (size_t)g * E.gd.cells;
     u64 h = 0x9E3779B97F4A7C15ULL;
     for (int i = 0; i < E.gd.cells; ++i) h = (h ^ (u64)((int)in[i] + 1)) * 0x100000001B3ULL;
@@ -599,6 +619,7 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
         AZ_REQUIRE(az_net_action_size(net) == gd.A, AZ_EINVAL, "network action size %d != game action size %d",
                    az_net_action_size(net), gd.A);
     az_engine *e = new az_engine();
+    e->h_ctr = nullptr; e->h_err = nullptr;
     e->cfg = *cfg; e->net = net; e->stream = (hipStream_t)stream; e->lockstep_iters = 0;
     EngDev &d = e->d;
     d.gd = gd; d.G = cfg->n_slots; d.C = cfg->node_capacity; d.A = gd.A; d.max_plies = cfg->max_plies;
@@ -612,7 +633,7 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
     A_(active, G); A_(root_fresh, G); A_(leaf, G); A_(leaf_p1, G); A_(leaf_m1, G); A_(leaf_player, G);
     A_(leaf_status, G); A_(leaf_winner, G);
     A_(nodes, NC);
-    A_(nn_in, G * gd.cells); A_(probs, G * gd.A); A_(value, G);
+    A_(nn_in, G * gd.cells); A_(probs, G * gd.A); A_(value, G); A_(row_of_slot, G); A_(batch_cnt, 4);
     A_(samp_idx, G * (size_t)d.max_plies);
     A_(o_state, S * gd.cells); A_(o_pi, S * gd.A); A_(o_z, S); A_(o_meta, S * 4); A_(o_visits, S * gd.A);
     A_(ctr, CTR_COUNT); A_(err, 1); A_(max_nodes, 1);
@@ -633,27 +654,30 @@ extern "C" void az_engine_destroy(az_engine *e) {
     delete e;
 }
 
-static int forward(az_engine *e) {
+// network over the compacted leaf rows [0, *cnt)
+static int forward(az_engine *e, const int *cnt) {
     EngDev &d = e->d;
     if (e->cfg.evaluator == AZ_EVAL_FAKE) {
-        hipLaunchKernelGGL(k_fakenet, grid_for(d.G, TB), dim3(TB), 0, e->stream, d);
+        hipLaunchKernelGGL(k_fakenet, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, cnt);
         return AZ_OK;
     }
-    return az_net_forward(e->net, d.nn_in, d.G, d.probs, d.value, e->stream);
+    return az_net_forward_dyn(e->net, d.nn_in, cnt, d.G, d.probs, d.value, e->stream);
 }
 
+// MCT.search for every active slot: one root-prior pass (mcts.py:231-233; empty unless a slot holds a
+// fresh root), then n_sim lock-steps of [backup+select -> network].
 static int do_search(az_engine *e, int n_sim) {
     EngDev &d = e->d;
     dim3 gg((unsigned)((d.G + GPB - 1) / GPB)), gb(256);
-    hipLaunchKernelGGL(k_root_prep, gg, gb, 0, e->stream, d);
-    AZ_TRY(forward(e));
-    hipLaunchKernelGGL(k_root_init, gg, gb, 0, e->stream, d);
+    hipLaunchKernelGGL(k_root_prep, gg, gb, 0, e->stream, d, 0, d.G);
+    AZ_TRY(forward(e, d.batch_cnt + 2));
+    hipLaunchKernelGGL(k_root_init, gg, gb, 0, e->stream, d, 0, d.G);
     for (int s = 0; s < n_sim; ++s) {
-        if (s == 0) hipLaunchKernelGGL((k_step<false, true>), gg, gb, 0, e->stream, d, s);
-        else hipLaunchKernelGGL((k_step<true, true>), gg, gb, 0, e->stream, d, s);
-        AZ_TRY(forward(e));
+        if (s == 0) hipLaunchKernelGGL((k_step<false, true>), gg, gb, 0, e->stream, d, s, 0, d.G);
+        else hipLaunchKernelGGL((k_step<true, true>), gg, gb, 0, e->stream, d, s, 0, d.G);
+        AZ_TRY(forward(e, d.batch_cnt + (s & 1)));
     }
-    hipLaunchKernelGGL((k_step<true, false>), gg, gb, 0, e->stream, d, n_sim);
+    hipLaunchKernelGGL((k_step<true, false>), gg, gb, 0, e->stream, d, n_sim, 0, d.G);
     e->lockstep_iters += n_sim + 1;
     AZ_HIP(hipGetLastError());
     return AZ_OK;

@@ -39,56 +39,85 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PLANE_STRIDE(x) ((((x) + 30) / 32) * 32 + 1)
 
 struct TrunkParams {
-    const float *w1, *b1;        // conv1 [9][32], [32]
+    const float *w1f, *b1;       // conv1 B-fragment order [3 k-steps][2][64] (taps 9..11 zero), bias [32]
     const float *wf[3], *cb[3];  // conv2..4 B-fragment order [9][8][2][64], bias [32]
 };
 
-// implicit-GEMM 3x3 convolution of one board on MFMA.
-//   in_lds : [32 ic][IN_PS] planes of width IN_W; output position p=(y,x) of a W_OUT-wide plane reads
-//            in[(y+ky)*IN_W + (x+kx)]  (a halo, if any, is part of the input plane)
-//   M = P_OUT positions (MT tiles of 16), N = 32 oc (2 tiles), K = 9 taps x 32 ic
-template <int P_OUT, int W_OUT, int IN_W, int IN_PS, int MT>
+#define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define A_RING 3  // A-operand LDS reads are issued this many k-steps ahead of the MFMAs that use them
+
+// implicit-GEMM 3x3 convolution of one board on MFMA: M = P_OUT positions (MT tiles of 16),
+// N = 32 oc (2 tiles), K = 9 taps x 32 ic walked tap-major.
+//   in_lds : [32 ic][IN_PS] planes of width IN_W.  PAD = 0: "valid" conv, output (y,x) reads in[(y+ky)*IN_W + x+kx].
+//            PAD = 1: "same" conv on an un-haloed plane: out-of-plane taps are read (from in-bounds
+//            LDS of the same wave) and replaced by 0 through a per-lane 9-bit validity mask.
+//   Weight fragments of one tap (8 k-steps x 2 oc tiles) sit in registers; the next tap's 16 coalesced
+//   dword loads are issued a whole tap ahead so L2 latency hides under the MFMAs.
+template <int P_OUT, int W_OUT, int H_OUT, int IN_W, int IN_PS, int PAD, int MT>
 AZ_D void conv_mfma(const float *in_lds, const float *__restrict__ wf, const float *__restrict__ bias, int lane,
                     f32x4 (&acc)[MT][2]) {
     const int m_lane = lane & 15, kq = lane >> 4;
     int abase[MT];
+    unsigned vmask[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int p = 16 * mt + m_lane;
         p = p < P_OUT ? p : P_OUT - 1;
-        abase[mt] = kq * IN_PS + (p / W_OUT) * IN_W + (p % W_OUT);
+        const int y = p / W_OUT, x = p % W_OUT;
+        abase[mt] = kq * IN_PS + y * IN_W + x - PAD * (IN_W + 1);
+        unsigned vm = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int iy = y + t / 3 - PAD, ix = x + t % 3 - PAD;
+            vm |= (unsigned)(iy >= 0 && iy < H_OUT + 2 - 2 * PAD && ix >= 0 && ix < W_OUT + 2 - 2 * PAD) << t;
+        }
+        vmask[mt] = vm;
     }
     const float *wl = wf + lane;
-    // weight fragments of one tap (8 k-steps x 2 oc tiles) live in registers; the next tap's 16
-    // coalesced dword loads are issued before this tap's MFMAs so L2 latency hides under them
-    float bcur[16], bnxt[16];
+    float bfr[2][16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bcur[i] = wl[i * 64];
+    for (int i = 0; i < 16; ++i) bfr[0][i] = wl[i * 64];
     const float bv0 = bias[m_lane], bv1 = bias[16 + m_lane];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         acc[mt][0] = (f32x4){bv0, bv0, bv0, bv0};
         acc[mt][1] = (f32x4){bv1, bv1, bv1, bv1};
     }
+    float ar[A_RING][MT];
+#define CONV_LOAD(c, mt) in_lds[abase[mt] + ((c) / 8 / 3) * IN_W + ((c) / 8 % 3) + 4 * ((c) % 8) * IN_PS]
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int toff = (tap / 3) * IN_W + (tap % 3);
-        if (tap < 8) {
+    for (int c = 0; c < A_RING; ++c)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bnxt[i] = wl[((tap + 1) * 16 + i) * 64];
+        for (int mt = 0; mt < MT; ++mt) ar[c][mt] = CONV_LOAD(c, mt);
+#pragma unroll
+    for (int c = 0; c < 72; ++c) {
+        const int tap = c / 8, j = c % 8;
+        if (j == 0 && tap < 8) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bfr[(tap + 1) & 1][i] = wl[((tap + 1) * 16 + i) * 64];
         }
+        float ac[MT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float a = in_lds[abase[mt] + toff + 4 * j * IN_PS];
-                acc[mt][0] = MFMA(a, bcur[2 * j + 0], acc[mt][0]);
-                acc[mt][1] = MFMA(a, bcur[2 * j + 1], acc[mt][1]);
-            }
+        for (int mt = 0; mt < MT; ++mt) {
+            float v = ar[c % A_RING][mt];
+            if (PAD) v = ((vmask[mt] >> tap) & 1u) ? v : 0.0f;
+            ac[mt] = v;
         }
+        if (c + A_RING < 72) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bcur[i] = bnxt[i];
+            for (int mt = 0; mt < MT; ++mt) ar[c % A_RING][mt] = CONV_LOAD(c + A_RING, mt);
+        }
+        // keep the loads above issued BEFORE this step's MFMAs (hipcc otherwise sinks them to their
+        // first use and every k-step stalls on LDS / L2 latency)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[mt][0] = MFMA(ac[mt], bfr[tap & 1][2 * j + 0], acc[mt][0]);
+            acc[mt][1] = MFMA(ac[mt], bfr[tap & 1][2 * j + 1], acc[mt][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
+#undef CONV_LOAD
 }
 
 template <int P_OUT, int OUT_PS, int MT>
@@ -105,66 +134,79 @@ AZ_D void store_relu_lds(float *out, int lane, const f32x4 (&acc)[MT][2]) {
             }
 }
 
-#define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
 template <int CH, int CW>
 struct TrunkGeom {
     static constexpr int P1 = CH * CW, PW = CW + 2, PH = CH + 2;
-    static constexpr int PS1 = PLANE_STRIDE(PH * PW), PS2 = PLANE_STRIDE(P1);
+    static constexpr int INP = ((PH * PW + 15) / 16) * 16;  // padded input plane (also the guard band in front of r1)
+    static constexpr int PS1 = PLANE_STRIDE(P1), PS2 = PLANE_STRIDE(P1);
     static constexpr int H3 = CH - 2, W3 = CW - 2, P3 = H3 * W3, PS3 = PLANE_STRIDE(P3);
     static constexpr int H4 = CH - 4, W4 = CW - 4, P4 = H4 * W4;
     static constexpr int MT2 = (P1 + 15) / 16, MT3 = (P3 + 15) / 16, MT4 = (P4 + 15) / 16;
-    static constexpr int WAVE_FLOATS = NCH * (PS1 + PS2);
+    static constexpr int WAVE_FLOATS = INP + NCH * (PS1 + PS2);
     static constexpr int LDS_BYTES = 4 * WAVE_FLOATS * 4;
     static_assert(PS3 <= PS1, "conv3 output reuses the conv1 region");
-    static_assert(PH * PW <= NCH * PS2, "input staging uses the conv2 region");
+    static_assert(INP >= CW + 1 && NCH * PS2 >= CW + 1, "guard bands around r1 for the masked out-of-plane reads");
 };
 
+// One wavefront per board; activations never leave the wave's private LDS region.
+//   inp : (CH+2)x(CW+2) zero-padded input plane           r1 : conv1 output [32][PS1], later conv3 output
+//   r2  : conv2 output [32][PS2]
+// 17 KB of LDS per wave -> two 4-wave blocks per CU, i.e. two waves per SIMD hide each other's
+// LDS/VALU phases behind MFMA work.
 template <int CH, int CW>
-__global__ __launch_bounds__(256) void k_trunk(const float *__restrict__ in, int B, TrunkParams tp, float *__restrict__ feat) {
+__global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, TrunkParams tp, float *__restrict__ feat) {
     using G = TrunkGeom<CH, CW>;
+    if (dyn_count) { int c = *dyn_count; B = c < B ? c : B; }  // rows actually filled this step
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wave;
     if (b >= B) return;  // waves are independent: no workgroup barrier below
-    float *r1 = smem + wave * G::WAVE_FLOATS;  // conv1 output (with zero halo), later conv3 output
-    float *r2 = r1 + NCH * G::PS1;             // padded input plane, later conv2 output
-    for (int i = lane; i < NCH * G::PS1; i += 64) r1[i] = 0.0f;
-    for (int i = lane; i < G::PH * G::PW; i += 64) r2[i] = 0.0f;
+    float *inp = smem + wave * G::WAVE_FLOATS;
+    float *r1 = inp + G::INP;
+    float *r2 = r1 + NCH * G::PS1;
+    for (int i = lane; i < G::INP; i += 64) inp[i] = 0.0f;
     LDS_FENCE();
-    for (int p = lane; p < G::P1; p += 64) r2[(p / CW + 1) * G::PW + (p % CW) + 1] = in[(size_t)b * G::P1 + p];
+    for (int p = lane; p < G::P1; p += 64) inp[(p / CW + 1) * G::PW + (p % CW) + 1] = in[(size_t)b * G::P1 + p];
     LDS_FENCE();
-    // conv1 1->32, pad 1 (othello.py:370): one lane per position, scalar weights
-    for (int p = lane; p < G::P1; p += 64) {
-        const int y = p / CW, x = p % CW;
-        float nb[9];
+    {  // conv1 1->32, pad 1 (othello.py:370) as a K = 12 MFMA product: taps 0..8, taps 9..11 carry zero weights
+        f32x4 acc[G::MT2][2];
+        const int m_lane = lane & 15, kq = lane >> 4;
+        const float bv0 = tp.b1[m_lane], bv1 = tp.b1[16 + m_lane];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) nb[t] = r2[(y + t / 3) * G::PW + x + t % 3];
-        for (int oc = 0; oc < NCH; ++oc) {
-            float acc = tp.b1[oc];
+        for (int s = 0; s < 3; ++s) {
+            int tap = 4 * s + kq;
+            tap = tap < 9 ? tap : 8;  // finite operand for the zero-weight columns
+            const int toff = (tap / 3) * G::PW + tap % 3;
+            const float b0 = tp.w1f[(s * 2 + 0) * 64 + lane], b1 = tp.w1f[(s * 2 + 1) * 64 + lane];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc = fmaf(nb[t], tp.w1[t * NCH + oc], acc);
-            r1[oc * G::PS1 + (y + 1) * G::PW + x + 1] = acc > 0.0f ? acc : 0.0f;
+            for (int mt = 0; mt < G::MT2; ++mt) {
+                int p = 16 * mt + m_lane;
+                p = p < G::P1 ? p : G::P1 - 1;
+                const float a = inp[(p / CW) * G::PW + (p % CW) + toff];
+                if (s == 0) { acc[mt][0] = (f32x4){bv0, bv0, bv0, bv0}; acc[mt][1] = (f32x4){bv1, bv1, bv1, bv1}; }
+                acc[mt][0] = MFMA(a, b0, acc[mt][0]);
+                acc[mt][1] = MFMA(a, b1, acc[mt][1]);
+            }
         }
+        store_relu_lds<G::P1, G::PS1, G::MT2>(r1, lane, acc);
     }
     LDS_FENCE();
-    {  // conv2 32->32, pad 1 (othello.py:371): reads the halo'd conv1 planes
+    {  // conv2 32->32, pad 1 (othello.py:371)
         f32x4 acc[G::MT2][2];
-        conv_mfma<G::P1, CW, G::PW, G::PS1, G::MT2>(r1, tp.wf[0], tp.cb[0], lane, acc);
-        LDS_FENCE();
+        conv_mfma<G::P1, CW, CH, CW, G::PS1, 1, G::MT2>(r1, tp.wf[0], tp.cb[0], lane, acc);
         store_relu_lds<G::P1, G::PS2, G::MT2>(r2, lane, acc);
     }
     LDS_FENCE();
     {  // conv3 32->32, valid (othello.py:372)
         f32x4 acc[G::MT3][2];
-        conv_mfma<G::P3, G::W3, CW, G::PS2, G::MT3>(r2, tp.wf[1], tp.cb[1], lane, acc);
+        conv_mfma<G::P3, G::W3, G::H3, CW, G::PS2, 0, G::MT3>(r2, tp.wf[1], tp.cb[1], lane, acc);
         LDS_FENCE();
         store_relu_lds<G::P3, G::PS3, G::MT3>(r1, lane, acc);
     }
     LDS_FENCE();
     {  // conv4 32->32, valid (othello.py:373) -> flattened NCHW features (othello.py:374)
         f32x4 acc[G::MT4][2];
-        conv_mfma<G::P4, G::W4, G::W3, G::PS3, G::MT4>(r1, tp.wf[2], tp.cb[2], lane, acc);
+        conv_mfma<G::P4, G::W4, G::H4, G::W3, G::PS3, 0, G::MT4>(r1, tp.wf[2], tp.cb[2], lane, acc);
         float *fo = feat + (size_t)b * (NCH * G::P4);
 #pragma unroll
         for (int mt = 0; mt < G::MT4; ++mt)
@@ -184,7 +226,10 @@ __global__ __launch_bounds__(256) void k_trunk(const float *__restrict__ in, int
 // before the current tile's 8 MFMA k-steps and written to the other buffer after them.
 template <int BM, int BN, int WM, int WN, bool RELU>
 __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const float *__restrict__ Bw,
-                                              const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K) {
+                                              const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
+                                              const int *__restrict__ dyn_count) {
+    if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
+    if ((int)blockIdx.y * BM >= M) return;  // whole block beyond the rows filled this step (uniform exit)
     constexpr int BK = 32, WAVES_N = BN / WN, TM = WM / 16, TN = WN / 16;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
     constexpr int ASTR = BK + 2;   // (2m + kq) mod 32 : conflict-free A-fragment reads
@@ -251,18 +296,32 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const
     for (int t = 0; t < T; ++t) {
         const bool more = t + 1 < T;
         if (more) GEMM_ISSUE((t + 1) * BK)
-        const float *as = As + (t & 1) * BM * ASTR, *bs = Bs + (t & 1) * BK * BSTR;
+        const float *as = As + (t & 1) * BM * ASTR + (wm0 + (lane & 15)) * ASTR + (lane >> 4);
+        const float *bs = Bs + (t & 1) * BK * BSTR + (lane >> 4) * BSTR + wn0 + (lane & 15);
+        float afn[TM], bfn[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) afn[tm] = as[tm * 16 * ASTR];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bfn[tn] = bs[tn * 16];
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             float af[TM], bf[TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) af[tm] = as[(wm0 + tm * 16 + (lane & 15)) * ASTR + ks * 4 + (lane >> 4)];
+            for (int tm = 0; tm < TM; ++tm) af[tm] = afn[tm];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bf[tn] = bs[(ks * 4 + (lane >> 4)) * BSTR + wn0 + tn * 16 + (lane & 15)];
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = bfn[tn];
+            if (ks + 1 < BK / 4) {  // next k-step's fragments are in flight while this one's MFMAs issue
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) afn[tm] = as[tm * 16 * ASTR + (ks + 1) * 4];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bfn[tn] = bs[(ks + 1) * 4 * BSTR + tn * 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA(af[tm], bf[tn], acc[tm][tn]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) GEMM_STORE((t + 1) & 1)
         __syncthreads();
@@ -293,64 +352,153 @@ constexpr int gemm_lds_bytes() { return 4 * (2 * BM * (32 + 2) + 2 * 32 * (BN + 
 // policy + value heads (othello.py:379-382, base.py:355): logits = h2 * Wh + bh with
 // Wh = [fc_probs | fc_value | 0-pad] of width NH = 16*NT; then softmax over the first A columns
 // and tanh of column A.  64 rows per block (4 waves x 16 rows).
+// 32 rows per block; wave w owns row tile (w >> 1) and the column tiles [0, NS) or [NS, NT) (NS = ceil(NT/2)).
+// K is walked in chunks of 128: the next chunk's X rows and Wh rows are fetched into registers (coalesced
+// 16-byte loads) while the current chunk's MFMAs run from LDS, so L2 latency is paid once per chunk;
+// inside a chunk the LDS fragment reads run one k-step ahead of the MFMAs.
 template <int NT>
 __global__ __launch_bounds__(256) void k_heads(const float *__restrict__ X, const float *__restrict__ Wh,
                                                const float *__restrict__ bh, int M, int K, int A,
-                                               float *__restrict__ probs, float *__restrict__ value) {
-    constexpr int NH = NT * 16, KC = 128, XSTR = KC + 2;
-    __shared__ __attribute__((aligned(16))) float Xs[64][XSTR];
-    __shared__ float Ls[64][NH + 1];
+                                               float *__restrict__ probs, float *__restrict__ value, const int *__restrict__ dyn_count) {
+    if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
+    if ((int)blockIdx.x * 32 >= M) return;
+    constexpr int NH = NT * 16, KC = 128, XSTR = KC + 2, WSTR = NH, NS = (NT + 1) / 2;  // NH = 16 (mod 32): conflict-free
+    constexpr int X_LD = 32 * KC / 4 / 256, W_LD = (KC * NH / 4 + 255) / 256;            // float4 per thread per chunk
+    static_assert(X_LD == 4 && W_LD <= 10, "staging registers");
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    float *Xs = hsm;                       // [32][XSTR]
+    float *Ws = Xs + 32 * XSTR;            // [KC][WSTR]
+    float *Ls = Ws + KC * WSTR;            // [32][NH + 1]
+    float *rsum = Ls + 32 * (NH + 1);      // [32]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int brow0 = blockIdx.x * 64;
-    f32x4 acc[NT];
+    const int brow0 = blockIdx.x * 32;
+    const int mt = wave >> 1, nt0 = (wave & 1) ? NS : 0, ntn = (wave & 1) ? NT - NS : NS;
+    f32x4 acc[NS];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { float bv = bh[nt * 16 + (lane & 15)]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
-    const float *bp = Wh + (size_t)(lane >> 4) * NH + (lane & 15);
-    const float *xa = &Xs[wave * 16 + (lane & 15)][lane >> 4];
+    for (int i = 0; i < NS; ++i) {
+        float bv = i < ntn ? bh[(nt0 + i) * 16 + (lane & 15)] : 0.0f;
+        acc[i] = (f32x4){bv, bv, bv, bv};
+    }
+    float4 rx[X_LD], rw[W_LD];
+#pragma unroll
+    for (int i = 0; i < X_LD; ++i) rx[i] = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) rw[i] = make_float4(0, 0, 0, 0);
+    // per-thread copy slots, computed once: X float4 #i is (row, q) with KC/4 = 32 per row; the Wh chunk
+    // [kc, kc+KC) x NH is one contiguous run of KC*NH floats both in HBM and in Ws (no index math)
+    const float *xsrc[X_LD];
+    int xq[X_LD], xdst[X_LD];
+#pragma unroll
+    for (int i = 0; i < X_LD; ++i) {
+        int idx = tid + i * 256, row = idx >> 5, q = idx & 31;
+        int gr = brow0 + row;
+        gr = gr < M ? gr : M - 1;
+        xsrc[i] = X + (size_t)gr * K + 4 * q;
+        xq[i] = 4 * q;
+        xdst[i] = row * XSTR + 4 * q;
+    }
+    auto issue = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < X_LD; ++i)
+            rx[i] = kc + xq[i] < K ? *reinterpret_cast<const float4 *>(xsrc[i] + kc) : make_float4(0, 0, 0, 0);
+        const float *wsrc = Wh + (size_t)kc * NH;
+        const int wlim = (K - kc) * NH;  // floats of Wh left from row kc on
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i) {
+            int f = 4 * (tid + i * 256);
+            if (f < KC * NH) rw[i] = f < wlim ? *reinterpret_cast<const float4 *>(wsrc + f) : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < X_LD; ++i) {
+            float *d = Xs + xdst[i];
+            *reinterpret_cast<float2 *>(d) = make_float2(rx[i].x, rx[i].y);
+            *reinterpret_cast<float2 *>(d + 2) = make_float2(rx[i].z, rx[i].w);
+        }
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i) {
+            int f = 4 * (tid + i * 256);
+            if (f < KC * NH) *reinterpret_cast<float4 *>(Ws + f) = rw[i];
+        }
+    };
+    issue(0);
+    int boff[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) boff[i] = i < ntn ? i * 16 : 0;
+    const float *xa = Xs + (mt * 16 + (lane & 15)) * XSTR + (lane >> 4);
+    const float *wb = Ws + (lane >> 4) * WSTR + nt0 * 16 + (lane & 15);
     for (int kc = 0; kc < K; kc += KC) {
-        const int kw = K - kc < KC ? K - kc : KC;  // chunk width (K is a multiple of 4)
+        stash();
         __syncthreads();
-        for (int idx = tid; idx < 64 * (KC / 4); idx += 256) {
-            int row = idx / (KC / 4), q = idx % (KC / 4);
-            int gr = brow0 + row;
-            gr = gr < M ? gr : M - 1;
-            if (4 * q < kw) {
-                float4 v = *reinterpret_cast<const float4 *>(X + (size_t)gr * K + kc + 4 * q);
-                float *d = &Xs[row][4 * q];
-                *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.y);
-                *reinterpret_cast<float2 *>(d + 2) = make_float2(v.z, v.w);
-            }
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int k0 = 0; k0 < kw; k0 += 4) {
-            float a = xa[k0];
+        if (kc + KC < K) issue(kc + KC);
+        float a_n = xa[0], b_n[NS];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = MFMA(a, bp[(size_t)(kc + k0) * NH + nt * 16], acc[nt]);
+        for (int i = 0; i < NS; ++i) b_n[i] = wb[boff[i]];
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            const float a = a_n;
+            float b[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) b[i] = b_n[i];
+            if (ks + 1 < KC / 4) {
+                a_n = xa[(ks + 1) * 4];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) b_n[i] = wb[(ks + 1) * 4 * WSTR + boff[i]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // uniform code for both wave kinds: a wave with fewer column tiles recomputes tile 0 into a
+            // spare accumulator (a predicated MFMA makes hipcc bounce accumulators through VGPRs)
+#pragma unroll
+            for (int i = 0; i < NS; ++i) acc[i] = MFMA(a, b[i], acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int i = 0; i < NS; ++i)
+        if (i < ntn)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ls[wave * 16 + (lane >> 4) * 4 + r][nt * 16 + (lane & 15)] = acc[nt][r];
+            for (int r = 0; r < 4; ++r) Ls[(mt * 16 + (lane >> 4) * 4 + r) * (NH + 1) + (nt0 + i) * 16 + (lane & 15)] = acc[i][r];
     __syncthreads();
-    if (tid < 64) {
-        int row = brow0 + tid;
-        if (row < M) {
-            float *l = Ls[tid];
-            float m = l[0];
-            for (int a = 1; a < A; ++a) m = l[a] > m ? l[a] : m;
-            float s = 0.0f;
-            for (int a = 0; a < A; ++a) { float e = az_det_expf(l[a] - m); l[a] = e; s += e; }
-            for (int a = 0; a < A; ++a) probs[(size_t)row * A + a] = l[a] / s;
-            value[row] = az_det_tanhf(l[A]);
+    // softmax (base.py:355 exp(log_softmax)): max and exp in parallel, the row sum sequentially in
+    // ascending action order (one lane per row) so that the result is reproducible bit for bit
+    const int row_l = tid >> 3, sub = tid & 7;  // 8 lanes per row
+    float *lrow = Ls + row_l * (NH + 1);
+    float m = -__builtin_inff();
+    for (int a = sub; a < A; a += 8) m = fmaxf(m, lrow[a]);
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 8));
+    const float vlogit = lrow[A];
+    for (int a = sub; a < A; a += 8) lrow[a] = az_det_expf(lrow[a] - m);
+    __syncthreads();
+    if (tid < 32) {
+        const float *l = Ls + tid * (NH + 1);
+        float s = 0.0f;
+        int a = 0;
+        for (; a + 8 <= A; a += 8) {
+            float t0 = l[a], t1 = l[a + 1], t2 = l[a + 2], t3 = l[a + 3], t4 = l[a + 4], t5 = l[a + 5], t6 = l[a + 6], t7 = l[a + 7];
+            s += t0; s += t1; s += t2; s += t3; s += t4; s += t5; s += t6; s += t7;
         }
+        for (; a < A; ++a) s += l[a];
+        rsum[tid] = s;
+    }
+    __syncthreads();
+    const int row = brow0 + row_l;
+    if (row < M) {
+        const float s = rsum[row_l];
+        for (int a = sub; a < A; a += 8) probs[(size_t)row * A + a] = lrow[a] / s;
+        if (sub == 0) value[row] = az_det_tanhf(vlogit);
     }
 }
 
+template <int NT>
+constexpr int heads_lds_bytes() { return 4 * (32 * (128 + 2) + 128 * NT * 16 + 32 * (NT * 16 + 1) + 32); }
+
 struct MlpParams { float f1w[81], f1b[9], f2w[81], f2b[9], hw[90], hb[10]; };
 
-__global__ void k_mlp(const float *__restrict__ in, int B, MlpParams p, float *__restrict__ probs, float *__restrict__ value) {
+__global__ void k_mlp(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, MlpParams p, float *__restrict__ probs, float *__restrict__ value) {
+    if (dyn_count) { int c = *dyn_count; B = c < B ? c : B; }
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float x[9], h1[9], h2[9], lg[10];
@@ -407,7 +555,7 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
         int rc = AZ_OK;
         float *p;
 #define NA(field, cnt) if (rc == AZ_OK) { rc = net_alloc(n, &p, (cnt)); field = p; }
-        NA(n->tp.w1, 9 * NCH) NA(n->tp.b1, NCH)
+        NA(n->tp.w1f, 3 * 2 * 64) NA(n->tp.b1, NCH)
         for (int l = 0; l < 3; ++l) { NA(n->tp.wf[l], 9 * 8 * 2 * 64) NA(n->tp.cb[l], NCH) }
         NA(n->fc1w, (size_t)n->FIN * n->F1) NA(n->fc1b, n->F1) NA(n->fc2w, (size_t)n->F1 * n->F2) NA(n->fc2b, n->F2)
         NA(n->hw, (size_t)n->F2 * n->NH) NA(n->hb, n->NH)
@@ -509,10 +657,15 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
         std::vector<float> fb(NCH);
         for (int oc = 0; oc < NCH; ++oc) fb[oc] = (float)(((double)(*b)[oc] - mean[oc]) * s[oc] + beta[oc]);
         if (l == 0) {
-            std::vector<float> fw(9 * NCH);
-            for (int oc = 0; oc < NCH; ++oc)
-                for (int t = 0; t < 9; ++t) fw[t * NCH + oc] = (float)((double)(*w)[oc * 9 + t] * s[oc]);
-            AZ_TRY(upload((float *)n->tp.w1, fw, st)); AZ_TRY(upload((float *)n->tp.b1, fb, st));
+            // MFMA B-fragment order [k-step s][nt][lane] = W'[oc = nt*16 + (lane&15)][tap = 4s + (lane>>4)], 0 for tap >= 9
+            std::vector<float> fw(3 * 2 * 64, 0.0f);
+            for (int sidx = 0; sidx < 3; ++sidx)
+                for (int nt = 0; nt < 2; ++nt)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        int oc = nt * 16 + (lane & 15), t = 4 * sidx + (lane >> 4);
+                        if (t < 9) fw[(sidx * 2 + nt) * 64 + lane] = (float)((double)(*w)[oc * 9 + t] * s[oc]);
+                    }
+            AZ_TRY(upload((float *)n->tp.w1f, fw, st)); AZ_TRY(upload((float *)n->tp.b1, fb, st));
         } else {
             // MFMA B-fragment order: [tap][j][nt][lane] = W'[oc = nt*16 + (lane&15)][ic = 4j + (lane>>4)][tap]
             std::vector<float> fw(9 * 8 * 2 * 64);
@@ -561,19 +714,19 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
 }
 
 template <int CH, int CW>
-static int launch_trunk(az_net *n, const float *in, int B, hipStream_t st) {
+static int launch_trunk(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
     using G = TrunkGeom<CH, CW>;
     static bool attr_set = false;
     if (!attr_set) {
         AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk<CH, CW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_trunk<CH, CW>), dim3((B + 3) / 4), dim3(256), G::LDS_BYTES, st, in, B, n->tp, n->feat);
+    hipLaunchKernelGGL((k_trunk<CH, CW>), dim3((B + 3) / 4), dim3(256), G::LDS_BYTES, st, in, B, dyn, n->tp, n->feat);
     return AZ_OK;
 }
 
 template <int BM, int BN, int WM, int WN>
-static int gemm_go(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, hipStream_t st) {
+static int gemm_go(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
     constexpr int lds = gemm_lds_bytes<BM, BN>();
     static bool attr_set = false;
     if (!attr_set) {
@@ -582,57 +735,80 @@ static int gemm_go(const float *A, const float *Bw, const float *bias, float *C,
         attr_set = true;
     }
     dim3 grid(N / BN, (M + BM - 1) / BM);
-    if (relu) hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K);
-    else hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K);
+    if (relu) hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+    else hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
     return AZ_OK;
 }
 
-static int launch_gemm(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, hipStream_t st) {
+static int launch_gemm(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
     AZ_REQUIRE(K % 32 == 0, AZ_EINVAL, "GEMM K=%d is not a multiple of 32", K);
-    if (N % 128 == 0) {
-        if ((long long)((M + 127) / 128) * (N / 128) >= 256) return gemm_go<128, 128, 64, 64>(A, Bw, bias, C, M, N, K, relu, st);
-        return gemm_go<64, 128, 32, 64>(A, Bw, bias, C, M, N, K, relu, st);
-    }
-    if (N % 64 == 0) return gemm_go<128, 64, 32, 64>(A, Bw, bias, C, M, N, K, relu, st);
-    if (N % 32 == 0) return gemm_go<128, 32, 32, 32>(A, Bw, bias, C, M, N, K, relu, st);
+    // pick the largest tile that still gives every CU two resident blocks (512 blocks on 256 CUs):
+    // a block's barrier and LDS-fill phases then overlap the other block's MFMAs
+    const long long mb128 = (M + 127) / 128, mb64 = (M + 63) / 64;
+    if (N % 128 == 0 && mb128 * (N / 128) >= 512) return gemm_go<128, 128, 64, 64>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+    if (N % 64 == 0 && mb128 * (N / 64) >= 512) return gemm_go<128, 64, 32, 64>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+    if (N % 64 == 0 && mb64 * (N / 64) >= 512) return gemm_go<64, 64, 32, 32>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+    if (N % 128 == 0) return gemm_go<64, 128, 32, 64>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+    if (N % 64 == 0) return gemm_go<64, 64, 32, 32>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+    if (N % 32 == 0) return gemm_go<128, 32, 32, 32>(A, Bw, bias, C, M, N, K, relu, dyn, st);
     az_set_error("GEMM N=%d is not a multiple of 32", N);
     return AZ_EINVAL;
 }
 
-static int launch_heads(az_net *n, int B, float *probs, float *value, hipStream_t st) {
-    dim3 grid((B + 63) / 64), bl(256);
-    switch (n->NH / 16) {
-        case 1: hipLaunchKernelGGL((k_heads<1>), grid, bl, 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, probs, value); break;
-        case 3: hipLaunchKernelGGL((k_heads<3>), grid, bl, 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, probs, value); break;
-        case 5: hipLaunchKernelGGL((k_heads<5>), grid, bl, 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, probs, value); break;
-        default: az_set_error("no heads kernel for padded width %d", n->NH); return AZ_EINVAL;
+template <int NT>
+static int heads_go(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
+    constexpr int lds = heads_lds_bytes<NT>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_heads<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
     }
+    hipLaunchKernelGGL((k_heads<NT>), dim3((B + 31) / 32), dim3(256), lds, st, n->h2, n->hw, n->hb, B, n->F2, n->A, probs, value, dyn);
     return AZ_OK;
 }
 
-static int run_stage(az_net *n, int stage, const float *d_input, int B, float *d_probs, float *d_value, hipStream_t st) {
-    switch (stage) {
-        case 0:
-            if (n->CH == 8 && n->CW == 8) return launch_trunk<8, 8>(n, d_input, B, st);
-            if (n->CH == 6 && n->CW == 6) return launch_trunk<6, 6>(n, d_input, B, st);
-            return launch_trunk<7, 6>(n, d_input, B, st);
-        case 1: return launch_gemm(n->feat, n->fc1w, n->fc1b, n->h1, B, n->F1, n->FIN, true, st);
-        case 2: return launch_gemm(n->h1, n->fc2w, n->fc2b, n->h2, B, n->F2, n->F1, true, st);
-        default: return launch_heads(n, B, d_probs, d_value, st);
+static int launch_heads(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
+    switch (n->NH / 16) {
+        case 1: return heads_go<1>(n, B, probs, value, dyn, st);
+        case 3: return heads_go<3>(n, B, probs, value, dyn, st);
+        case 5: return heads_go<5>(n, B, probs, value, dyn, st);
+        default: az_set_error("no heads kernel for padded width %d", n->NH); return AZ_EINVAL;
     }
 }
 
-extern "C" int az_net_forward(az_net *n, const float *d_input, int B, float *d_probs, float *d_value, void *stream) {
+static int run_stage(az_net *n, int stage, const float *d_input, int B, const int *dyn, float *d_probs, float *d_value, hipStream_t st) {
+    switch (stage) {
+        case 0:
+            if (n->CH == 8 && n->CW == 8) return launch_trunk<8, 8>(n, d_input, B, dyn, st);
+            if (n->CH == 6 && n->CW == 6) return launch_trunk<6, 6>(n, d_input, B, dyn, st);
+            return launch_trunk<7, 6>(n, d_input, B, dyn, st);
+        case 1: return launch_gemm(n->feat, n->fc1w, n->fc1b, n->h1, B, n->F1, n->FIN, true, dyn, st);
+        case 2: return launch_gemm(n->h1, n->fc2w, n->fc2b, n->h2, B, n->F2, n->F1, true, dyn, st);
+        default: return launch_heads(n, B, d_probs, d_value, dyn, st);
+    }
+}
+
+static int forward_impl(az_net *n, const float *d_input, int B, const int *dyn, float *d_probs, float *d_value, void *stream) {
     AZ_REQUIRE(n && d_input && d_probs && d_value, AZ_EINVAL, "null argument");
     AZ_REQUIRE(n->committed, AZ_ESTATE, "az_net_commit has not been called since the last az_net_set_tensor");
     AZ_REQUIRE(B > 0 && B <= n->max_batch, AZ_EINVAL, "batch %d outside (0, max_batch=%d]", B, n->max_batch);
     hipStream_t st = (hipStream_t)stream;
     if (n->game == AZ_TICTACTOE) {
-        hipLaunchKernelGGL(k_mlp, dim3((B + 63) / 64), dim3(64), 0, st, d_input, B, n->mlp, d_probs, d_value);
+        hipLaunchKernelGGL(k_mlp, dim3((B + 63) / 64), dim3(64), 0, st, d_input, B, dyn, n->mlp, d_probs, d_value);
         return AZ_OK;
     }
-    for (int s = 0; s < 4; ++s) AZ_TRY(run_stage(n, s, d_input, B, d_probs, d_value, st));
+    for (int s = 0; s < 4; ++s) AZ_TRY(run_stage(n, s, d_input, B, dyn, d_probs, d_value, st));
     return AZ_OK;
+}
+
+extern "C" int az_net_forward(az_net *n, const float *d_input, int B, float *d_probs, float *d_value, void *stream) {
+    return forward_impl(n, d_input, B, nullptr, d_probs, d_value, stream);
+}
+
+extern "C" int az_net_forward_dyn(az_net *n, const float *d_input, const int32_t *d_count, int max_B, float *d_probs,
+                                  float *d_value, void *stream) {
+    AZ_REQUIRE(d_count, AZ_EINVAL, "null count pointer");
+    return forward_impl(n, d_input, max_B, d_count, d_probs, d_value, stream);
 }
 
 extern "C" int az_net_time_stage(az_net *n, int stage, int B, int iters, void *stream, float *ms_per_launch) {
@@ -651,7 +827,7 @@ extern "C" int az_net_time_stage(az_net *n, int stage, int B, int iters, void *s
     int rc = AZ_OK;
     for (int it = -2; it < iters && rc == AZ_OK; ++it) {  // two untimed warm-up launches
         if (it == 0) (void)hipEventRecord(e0, st);
-        rc = stage < 0 ? az_net_forward(n, in, B, pr, va, st) : run_stage(n, stage, in, B, pr, va, st);
+        rc = stage < 0 ? az_net_forward(n, in, B, pr, va, st) : run_stage(n, stage, in, B, nullptr, pr, va, st);
     }
     (void)hipEventRecord(e1, st);
     (void)hipEventSynchronize(e1);

@@ -81,6 +81,10 @@ int az_net_commit(az_net *net, void *stream);
 /* d_input[B][H*W] float32 canonical boards (player*grid, base.py:363);
  * d_probs[B][A] = exp(log_softmax) policy, d_value[B] = tanh value. */
 int az_net_forward(az_net *net, const float *d_input, int B, float *d_probs, float *d_value, void *stream);
+/* same, but only the first min(*d_count, max_B) rows are evaluated: d_count is a DEVICE int written by an
+ * earlier kernel on `stream` (the engine compacts the leaves that need an evaluation into the front rows). */
+int az_net_forward_dyn(az_net *net, const float *d_input, const int32_t *d_count, int max_B, float *d_probs,
+                       float *d_value, void *stream);
 int az_net_action_size(const az_net *net);
 /* algorithmic FLOPs of one forward per board (2*MAC) */
 int64_t az_net_flops_per_board(const az_net *net);
