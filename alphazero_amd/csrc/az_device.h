@@ -293,6 +293,73 @@ AZ_D bool az_status(const GameDesc& gd, const BB& b, int* winner) {
     return false;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 16-lane cooperative variants (engine tree walk: 16 lanes per game).  The 8 flood directions of the
+// Othello rules go to 8 lanes (lanes 8..15 mirror them for the other colour where that helps), the
+// partial bitboards are OR-reduced with three width-8 shuffles.  All 16 lanes must call these together
+// and all get the full result.
+// ---------------------------------------------------------------------------------------------
+struct DirLane {  // this lane's direction: 0 E, 1 S, 2 SE, 3 SW, 4 W, 5 N, 6 NW, 7 NE
+    int amt;
+    bool left;
+    u64 mask;
+};
+AZ_D DirLane az_dir_lane(int sub) {
+    const int d = sub & 7, k = d & 3;
+    DirLane L;
+    L.amt = k == 0 ? 1 : (k == 1 ? 8 : (k == 2 ? 9 : 7));
+    L.left = d < 4;
+    // E, SE, NE must not wrap into column 0; W, NW, SW must not wrap into column 7
+    const bool to_col0 = (d == 0 || d == 2 || d == 7), to_col7 = (d == 4 || d == 6 || d == 3);
+    L.mask = to_col0 ? ~AZ_COL0 : (to_col7 ? ~AZ_COL7 : ~0ULL);
+    return L;
+}
+AZ_D u64 dsh(const DirLane& L, u64 x) { return (L.left ? (x << L.amt) : (x >> L.amt)) & L.mask; }
+AZ_D u64 or8(u64 v) {
+    v |= (u64)__shfl_xor((long long)v, 1, 8);
+    v |= (u64)__shfl_xor((long long)v, 2, 8);
+    v |= (u64)__shfl_xor((long long)v, 4, 8);
+    return v;
+}
+AZ_D u64 oth_legal_dir(const DirLane& L, u64 own, u64 opp, u64 empty) {
+    u64 x = dsh(L, own) & opp;
+    x |= dsh(L, x) & opp; x |= dsh(L, x) & opp; x |= dsh(L, x) & opp; x |= dsh(L, x) & opp; x |= dsh(L, x) & opp;
+    return dsh(L, x) & empty;
+}
+// legal action bits of `player` (see az_legal_bits)
+AZ_D u64 az_legal_bits_grp(const GameDesc& gd, const BB& b, int player, int sub) {
+    if (gd.game != AZ_OTHELLO) return az_legal_bits(gd, b, player);
+    u64 own = player > 0 ? b.p1 : b.m1, opp = player > 0 ? b.m1 : b.p1;
+    return or8(oth_legal_dir(az_dir_lane(sub), own, opp, ~(own | opp) & gd.valid));
+}
+AZ_D void az_play_grp(const GameDesc& gd, BB& b, int action, int sub) {
+    if (gd.game != AZ_OTHELLO) { az_play(gd, b, action); return; }
+    u64 own = b.player > 0 ? b.p1 : b.m1, opp = b.player > 0 ? b.m1 : b.p1;
+    if (action != gd.cells) {
+        const DirLane L = az_dir_lane(sub);
+        const u64 mv = 1ULL << az_action_to_bit(gd, action);
+        u64 x = dsh(L, mv) & opp;
+        x |= dsh(L, x) & opp; x |= dsh(L, x) & opp; x |= dsh(L, x) & opp; x |= dsh(L, x) & opp; x |= dsh(L, x) & opp;
+        const u64 f = or8((dsh(L, x) & own) ? x : 0ULL);
+        own |= mv | f;
+        opp &= ~f;
+    }
+    if (b.player > 0) { b.p1 = own; b.m1 = opp; } else { b.m1 = own; b.p1 = opp; }
+    b.player = -b.player;
+}
+AZ_D bool az_status_grp(const GameDesc& gd, const BB& b, int* winner, int sub) {
+    if (gd.game != AZ_OTHELLO) return az_status(gd, b, winner);
+    // lanes 0..7 flood for player +1, lanes 8..15 for player -1
+    const bool second = (sub & 8) != 0;
+    const u64 own = second ? b.m1 : b.p1, opp = second ? b.p1 : b.m1;
+    u64 any = or8(oth_legal_dir(az_dir_lane(sub), own, opp, ~(own | opp) & gd.valid));
+    any |= (u64)__shfl_xor((long long)any, 8, 16);
+    if (any) return false;
+    int d = __popcll(b.p1) - __popcll(b.m1);
+    *winner = d > 0 ? 1 : (d < 0 ? -1 : 0);
+    return true;
+}
+
 AZ_D int az_cell_value(const BB& b, int r, int c) {
     u64 bit = 1ULL << (r * 8 + c);
     return (b.p1 & bit) ? 1 : ((b.m1 & bit) ? -1 : 0);

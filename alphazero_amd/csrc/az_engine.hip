@@ -6,8 +6,10 @@
 //
 // HBM layout
 //   boards   : 2 x u64 bitboards + int8 side-to-move per slot (root and current leaf), SoA over slots
-//   tree     : per-slot bump-allocated pool of `C` 32-byte nodes (one node = two 16-byte accesses;
-//              a node's children are contiguous, so 16 lanes read 16 children as one 512-byte run):
+//   tree     : per slot two pools of `C` 32-byte nodes (one node = two 16-byte accesses; a node's children
+//              are contiguous, so 16 lanes read 16 children as one 512-byte run).  Nodes are bump-allocated
+//              during a search; at every move the kept subtree is copied breadth-first into the other pool
+//              (change_root, mcts.py:118-125), so a game's live tree stays a few hundred KB, contiguous:
 //              { f64 Q, f64 P, i32 N, i32 parent, i32 first_child, u8 n_children, u8 action, u8 flags, i8 winner }
 //   net i/o  : nn_in[G][cells] f32 canonical leaf boards, probs[G][A] f32, value[G] f32
 //   samples  : state i8[S][cells], pi f32[S][A], z i8[S], meta i32[S][4], visits i32[S][A]
@@ -66,7 +68,9 @@ struct EngDev {
     u64 *root_p1, *root_m1; int8_t *root_player;
     int *root, *n_nodes, *ply; u32 *game_id; uint8_t *active, *root_fresh;
     int *leaf; u64 *leaf_p1, *leaf_m1; int8_t *leaf_player, *leaf_status, *leaf_winner;
-    Node *nodes;
+    int *path, *path_len;  // root..leaf node indices of the pending simulation ([G][LPG]; longer paths chase parents)
+    Node *nodes;        // [G][2][C]
+    uint8_t *pool_sel;  // which of the slot's two pools holds the live tree
     float *nn_in, *probs, *value;
     int *row_of_slot;  // network batch row holding the slot's pending leaf (leaves are compacted)
     int *batch_cnt;    // [3] rows filled: two alternating lock-step counters + the root-prior pass
@@ -106,6 +110,8 @@ AZ_D Node fresh_node(int action, int parent, double P, int flags) {
     n.flags = (uint8_t)flags; n.win = 0;
     return n;
 }
+
+AZ_D Node *pool_of(const EngDev &E, int g) { return E.nodes + ((size_t)g * 2 + E.pool_sel[g]) * E.C; }
 
 AZ_D u32 grp_ballot(bool p) { return (u32)(__ballot(p) >> (threadIdx.x & 48)) & 0xFFFFu; }
 AZ_D double grp_max(double v) {
@@ -149,8 +155,8 @@ AZ_D void write_nn_input_grp(const EngDev &E, int row, const BB &b, int sub) {
 // one lane per legal action bit; returns false on pool exhaustion
 AZ_D bool create_children_grp(const EngDev &E, int g, int node, const BB &bb, const float *pr, int sub) {
     const GameDesc &gd = E.gd;
-    Node *pool = E.nodes + (size_t)g * E.C;
-    u64 bits = az_legal_bits(gd, bb, bb.player);
+    Node *pool = pool_of(E, g);
+    u64 bits = az_legal_bits_grp(gd, bb, bb.player, sub);
     bool pass = (gd.game == AZ_OTHELLO && bits == 0);
     int k = pass ? 1 : __popcll(bits);
     int fc = E.n_nodes[g];
@@ -182,18 +188,25 @@ AZ_D bool create_children_grp(const EngDev &E, int g, int node, const BB &bb, co
     return true;
 }
 
-// fair_max over PUCT (mcts.py:44-46, 137; utils.py:28-34): one lane per child, 16 children per round
-AZ_D int pick_child_grp(const EngDev &E, int g, const Node *pool, const Node &parent, int ply, int sim, int depth, int sub) {
+// fair_max over PUCT (mcts.py:44-46, 137; utils.py:28-34): one lane per child, 16 children per round.
+// The chosen child's node is handed back by shuffle from the lane that scored it (no second memory trip).
+AZ_D int pick_child_grp(const EngDev &E, int g, const Node *pool, const Node &parent, int ply, int sim, int depth, int sub,
+                        Node &chosen) {
     const int fc = parent.first, nc = parent.nch;
     const double sq = sqrt((double)parent.N);
     double key[4];
+    int cN[4], cfirst[4];
+    u32 cpack[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         key[r] = -__builtin_inf();
+        cN[r] = 0; cfirst[r] = -1; cpack[r] = 0;
         int i = r * LPG + sub;
         if (i < nc) {
             Node c = load_node(pool + fc + i);
             key[r] = c.Q + (c.P * sq) / (double)(1 + c.N);
+            cN[r] = c.N; cfirst[r] = c.first;
+            cpack[r] = (u32)c.nch | ((u32)c.act << 8) | ((u32)c.flags << 16) | ((u32)(uint8_t)c.win << 24);
         }
     }
     double best = grp_max(fmax(fmax(key[0], key[1]), fmax(key[2], key[3])));
@@ -202,17 +215,30 @@ AZ_D int pick_child_grp(const EngDev &E, int g, const Node *pool, const Node &pa
 #pragma unroll
     for (int r = 0; r < 4; ++r) { mask[r] = grp_ballot(key[r] == best); cnt += __popc(mask[r]); }
     int k = 0;
-    if (E.tie_mode == AZ_TIE_RANDOM) {
+    if (E.tie_mode == AZ_TIE_RANDOM && cnt > 1) {  // with a single maximum the draw cannot change the result
         Philox4 rr = az_philox(E.seed, E.game_id[g], (u32)ply, (u32)sim, AZ_P_TIE_SELECT, (u32)depth);
         k = (int)(((u64)rr.x * (u64)cnt) >> 32);
     }
+    int rsel = 0, lsel = 0;
+    bool found = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         int pc = __popc(mask[r]);
-        if (k < pc) return fc + r * LPG + kth_set_bit(mask[r], k);
-        k -= pc;
+        if (!found) {
+            if (k < pc) { rsel = r; lsel = kth_set_bit(mask[r], k); found = true; }
+            else k -= pc;
+        }
     }
-    return fc;
+    const int vN = rsel == 0 ? cN[0] : (rsel == 1 ? cN[1] : (rsel == 2 ? cN[2] : cN[3]));
+    const int vF = rsel == 0 ? cfirst[0] : (rsel == 1 ? cfirst[1] : (rsel == 2 ? cfirst[2] : cfirst[3]));
+    const u32 vP = rsel == 0 ? cpack[0] : (rsel == 1 ? cpack[1] : (rsel == 2 ? cpack[2] : cpack[3]));
+    chosen.N = __shfl(vN, lsel, LPG);
+    chosen.first = __shfl(vF, lsel, LPG);
+    const u32 pk = (u32)__shfl((int)vP, lsel, LPG);
+    chosen.nch = (uint8_t)(pk & 0xff); chosen.act = (uint8_t)((pk >> 8) & 0xff); chosen.flags = (uint8_t)((pk >> 16) & 0xff);
+    chosen.win = (int8_t)(pk >> 24);
+    chosen.Q = 0.0; chosen.P = 0.0; chosen.parent = 0;  // not needed by the walk
+    return fc + rsel * LPG + lsel;
 }
 
 AZ_D double log_gamma_draw(const EngDev &E, u32 gid, int ply, int sim, double alpha, u32 j) {
@@ -285,10 +311,26 @@ AZ_D void apply_root_noise_grp(const EngDev &E, int g, Node *pool, int root, con
     if (sub == 0) pool[root].flags = rn.flags | F_NOISED;
 }
 
-AZ_D void back_propagate_grp(Node *pool, int node, int player_to_play, double outcome, int sub) {  // mcts.py:197-223
+// back_propagate (mcts.py:197-223).  The select step recorded the root..leaf path, so every node on it
+// is updated by its own lane in one memory round trip (reward sign alternates from the leaf up);
+// paths longer than 16 nodes fall back to chasing parent pointers.
+AZ_D void back_propagate_grp(const EngDev &E, int g, Node *pool, int leaf, int player_to_play, double outcome, int sub) {
     double reward;
     if (fabs(outcome) < 1e-4) reward = 0.0;
     else reward = ((double)player_to_play * outcome > 0.0) ? -fabs(outcome) : fabs(outcome);
+    const int len = E.path_len[g];
+    if (len <= LPG) {
+        if (sub < len) {
+            const int node = E.path[(size_t)g * LPG + sub];
+            const int up = len - 1 - sub;  // edges above the leaf
+            Node n = load_node(pool + node);
+            const double r = (reward == 0.0) ? 0.0 : ((up & 1) ? -reward : reward);
+            pool[node].Q = ((double)n.N * n.Q + r) / (double)(n.N + 1);
+            pool[node].N = n.N + 1;
+        }
+        return;
+    }
+    int node = leaf;
     while (node >= 0) {
         Node n = load_node(pool + node);  // same address in all 16 lanes: one broadcast transaction
         if (sub == 0) {
@@ -306,7 +348,7 @@ AZ_D void reset_slot(const EngDev &E, int g, u32 game_id) {
     E.root_p1[g] = b.p1; E.root_m1[g] = b.m1; E.root_player[g] = (int8_t)b.player;
     E.root[g] = 0; E.n_nodes[g] = 1; E.ply[g] = 0; E.game_id[g] = game_id; E.active[g] = 1;
     E.leaf_status[g] = LS_NONE;
-    store_node(E.nodes + (size_t)g * E.C, fresh_node(0, -1, 0.0, 0));
+    store_node(pool_of(E, g), fresh_node(0, -1, 0.0, 0));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -323,6 +365,7 @@ __global__ void k_reset_all(EngDev E, u32 first_id, int n_games) {
         E.batch_cnt[0] = E.batch_cnt[1] = E.batch_cnt[2] = 0;
     }
     if (g >= E.G) return;
+    E.pool_sel[g] = 0;
     if (g < n_games) reset_slot(E, g, first_id + (u32)g);
     else { E.active[g] = 0; E.leaf_status[g] = LS_NONE; }
 }
@@ -333,7 +376,7 @@ __global__ __launch_bounds__(256) void k_root_prep(EngDev E, int g0, int g1) {
     if (g >= g1) return;
     uint8_t fresh = 0;
     if (E.active[g]) {
-        uint8_t f = E.nodes[(size_t)g * E.C + E.root[g]].flags;
+        uint8_t f = pool_of(E, g)[E.root[g]].flags;
         if (!(f & (F_EVALUATED | F_TERMINAL))) {
             fresh = 1;
         }
@@ -367,7 +410,7 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
     // previous step's network kernels, which have completed) is cleared for the next step
     if (blockIdx.x == 0 && threadIdx.x == 0 && g0 == 0) { E.batch_cnt[(sim + 1) & 1] = 0; if (!SELECT) E.batch_cnt[2] = 0; }
     if (g >= g1) return;
-    Node *pool = E.nodes + (size_t)g * E.C;
+    Node *pool = pool_of(E, g);
     if (BACKUP) {
         int st = E.leaf_status[g];
         if (st != LS_NONE) {
@@ -383,7 +426,7 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
             } else {
                 outcome = (double)E.leaf_winner[g];
             }
-            if (ok) back_propagate_grp(pool, node, b.player, outcome, sub);
+            if (ok) back_propagate_grp(E, g, pool, node, b.player, outcome, sub);
             if (sub == 0) E.leaf_status[g] = LS_NONE;
         }
         // the group's own stores (other lanes) must be visible to the loads below
@@ -400,14 +443,17 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
         cur.flags |= F_NOISED;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
-    int depth = 0;
+    int depth = 0, plen = 1;
+    int my_path = sub == 0 ? node : -1;  // lane i keeps the i-th node of the root..leaf path
     bool bad = false;
     for (;;) {
         if (cur.flags & F_EXPANDED) {
-            int c = pick_child_grp(E, g, pool, cur, ply, sim, depth++, sub);
-            node = c;
-            cur = load_node(pool + c);
-            az_play(E.gd, b, cur.act);
+            Node ch;
+            int c = pick_child_grp(E, g, pool, cur, ply, sim, depth++, sub, ch);
+            node = c; cur = ch;
+            if (sub == plen) my_path = c;
+            ++plen;
+            az_play_grp(E.gd, b, cur.act, sub);
             if (cur.N == 0) break;  // mcts.py:143-144
             continue;
         }
@@ -415,16 +461,20 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
         if (!(cur.flags & F_EVALUATED)) { bad = true; break; }
         cur.flags |= F_EXPANDED;  // mcts.py:151-160 : children become visible now
         if (sub == 0) pool[node].flags = cur.flags;
-        int c = pick_child_grp(E, g, pool, cur, ply, sim, depth, sub);
-        node = c;
-        cur = load_node(pool + c);
-        az_play(E.gd, b, cur.act);
+        Node ch;
+        int c = pick_child_grp(E, g, pool, cur, ply, sim, depth, sub, ch);
+        node = c; cur = ch;
+        if (sub == plen) my_path = c;
+        ++plen;
+        az_play_grp(E.gd, b, cur.act, sub);
         break;
     }
+    E.path[(size_t)g * LPG + sub] = my_path;
+    if (sub == 0) E.path_len[g] = plen;
     if (bad) { if (sub == 0) { atomicOr(E.err, ERR_INTERNAL); E.leaf_status[g] = LS_NONE; } return; }
     int status, w = 0;
     if (cur.flags & F_TERMINAL) { status = LS_TERM; w = cur.win; }
-    else if (az_status(E.gd, b, &w)) {  // mcts.py:185-186
+    else if (az_status_grp(E.gd, b, &w, sub)) {  // mcts.py:185-186
         status = LS_TERM;
         if (sub == 0) { pool[node].flags = cur.flags | F_TERMINAL; pool[node].win = (int8_t)w; }
     } else {
@@ -452,7 +502,7 @@ __global__ void k_move(EngDev E) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.G || !E.active[g]) return;
     const GameDesc &gd = E.gd;
-    Node *pool = E.nodes + (size_t)g * E.C;
+    Node *pool = pool_of(E, g);
     int ply = E.ply[g], root = E.root[g];
     u32 gid = E.game_id[g];
     BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
@@ -532,6 +582,54 @@ __global__ void k_move(EngDev E) {
         unsigned long long nx = atomicAdd(&E.ctr[CTR_NEXT_GAME], 1ULL);
         if (nx < E.ctr[CTR_TOTAL_GAMES]) reset_slot(E, g, (u32)E.ctr[CTR_FIRST_ID] + (u32)nx);
         else E.active[g] = 0;
+    }
+}
+
+// change_root (mcts.py:118-125) as a compaction: the subtree under the new root (E.root[g], set by k_move) is
+// copied breadth-first into the slot's other pool and becomes node 0.  While a node waits in the queue its
+// `first` field still holds the OLD index of its children; when its level is processed the children are copied
+// to a freshly bump-allocated block and `first` is rewritten.  16 lanes take 16 queue nodes per round.
+__global__ __launch_bounds__(256) void k_reroot(EngDev E) {
+    const int g = blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
+    if (g >= E.G || !E.active[g]) return;
+    const int sel = E.pool_sel[g];
+    const Node *src = E.nodes + ((size_t)g * 2 + sel) * E.C;
+    Node *dst = E.nodes + ((size_t)g * 2 + (sel ^ 1)) * E.C;
+    if (sub == 0) {
+        Node r = load_node(src + E.root[g]);
+        r.parent = -1;
+        store_node(dst, r);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    int lo = 0, hi = 1, next = 1;
+    bool overflow = false;
+    while (lo < hi && !overflow) {
+        for (int base = lo; base < hi; base += LPG) {
+            const int i = base + sub;
+            int cnt = 0, oldfc = 0;
+            if (i < hi) { Node nd = load_node(dst + i); cnt = nd.nch; oldfc = nd.first; }
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < LPG; d <<= 1) { int y = __shfl_up(incl, d, LPG); if (sub >= d) incl += y; }
+            const int total = __shfl(incl, LPG - 1, LPG);
+            const int newfc = next + incl - cnt;
+            if (next + total > E.C) { overflow = true; break; }
+            if (cnt > 0) {
+                for (int j = 0; j < cnt; ++j) {
+                    Node c = load_node(src + oldfc + j);
+                    c.parent = i;
+                    store_node(dst + newfc + j, c);
+                }
+                dst[i].first = newfc;
+            }
+            next += total;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        lo = hi; hi = next;
+    }
+    if (sub == 0) {
+        if (overflow) { atomicOr(E.err, ERR_NODE_POOL); E.active[g] = 0; }
+        E.root[g] = 0; E.n_nodes[g] = next; E.pool_sel[g] = (uint8_t)(sel ^ 1);
     }
 }
 
@@ -631,8 +729,8 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
 #define A_(p, n) if (rc == AZ_OK) rc = dev_alloc(e, &d.p, (n))
     A_(root_p1, G); A_(root_m1, G); A_(root_player, G); A_(root, G); A_(n_nodes, G); A_(ply, G); A_(game_id, G);
     A_(active, G); A_(root_fresh, G); A_(leaf, G); A_(leaf_p1, G); A_(leaf_m1, G); A_(leaf_player, G);
-    A_(leaf_status, G); A_(leaf_winner, G);
-    A_(nodes, NC);
+    A_(leaf_status, G); A_(leaf_winner, G); A_(path, G * LPG); A_(path_len, G);
+    A_(nodes, 2 * NC); A_(pool_sel, G);
     A_(nn_in, G * gd.cells); A_(probs, G * gd.A); A_(value, G); A_(row_of_slot, G); A_(batch_cnt, 4);
     A_(samp_idx, G * (size_t)d.max_plies);
     A_(o_state, S * gd.cells); A_(o_pi, S * gd.A); A_(o_z, S); A_(o_meta, S * 4); A_(o_visits, S * gd.A);
@@ -709,6 +807,7 @@ extern "C" int az_engine_run(az_engine *e, uint32_t first_game_id, int32_t n_gam
     for (long long it = 0; it < max_iters; ++it) {
         AZ_TRY(do_search(e, e->cfg.n_sim));
         hipLaunchKernelGGL(k_move, grid_for(d.G, TB), dim3(TB), 0, e->stream, d);
+        hipLaunchKernelGGL(k_reroot, dim3((unsigned)((d.G + GPB - 1) / GPB)), dim3(256), 0, e->stream, d);
         AZ_TRY(fetch_counters(e));
         AZ_TRY(check_err(e));
         if (e->h_ctr[CTR_GAMES_DONE] >= (unsigned long long)n_games) return AZ_OK;
@@ -789,6 +888,7 @@ extern "C" int az_engine_advance(az_engine *e) {
     EngDev &d = e->d;
     // games that end here must not be refilled: cap the queue at what has been started
     hipLaunchKernelGGL(k_move, grid_for(d.G, TB), dim3(TB), 0, e->stream, d);
+    hipLaunchKernelGGL(k_reroot, dim3((unsigned)((d.G + GPB - 1) / GPB)), dim3(256), 0, e->stream, d);
     AZ_TRY(fetch_counters(e));
     return check_err(e);
 }
@@ -800,7 +900,9 @@ extern "C" int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_ac
     AZ_REQUIRE(slot >= 0 && slot < d.G, AZ_EINVAL, "slot out of range");
     AZ_HIP(hipStreamSynchronize(e->stream));
     int root = 0;
-    size_t base = (size_t)slot * d.C;
+    uint8_t sel = 0;
+    AZ_HIP(hipMemcpy(&sel, d.pool_sel + slot, 1, hipMemcpyDeviceToHost));
+    size_t base = ((size_t)slot * 2 + sel) * d.C;
     AZ_HIP(hipMemcpy(&root, d.root + slot, sizeof(int), hipMemcpyDeviceToHost));
     Node rn;
     AZ_HIP(hipMemcpy(&rn, d.nodes + base + root, sizeof(Node), hipMemcpyDeviceToHost));

@@ -137,8 +137,9 @@ class SelfPlayEngine:
         if max_plies is None:
             max_plies = 2 * cells if game_id == 0 else cells + 1
         if node_capacity is None:
-            # bump allocation without compaction: one game allocates <= plies * n_sim * branching nodes
-            node_capacity = max(2048, min(1 << 18, int(max_plies * n_sim * (10 if game_id == 0 else 7) * 0.6)))
+            # per pool: the subtree kept at a move + everything one search allocates (the tree is compacted
+            # into the slot's other pool at every move); exhaustion is reported, never silent
+            node_capacity = max(4096, min(1 << 17, 96 * n_sim))
         if sample_capacity is None:
             sample_capacity = n_slots * max_plies
         self.cfg = EngineCfg(game_id, H, W, n_slots, n_sim,

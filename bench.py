@@ -74,7 +74,7 @@ def main():
     hnet = model.to_hip(max_batch=G)
     eng = E.SelfPlayEngine(0, n, n, n_slots=G, n_sim=args.sims, net=hnet, dirichlet_alpha=0.03, dirichlet_epsilon=0.25,
                            temp_max_step=4, temp_min_step=4, tie_mode=E.TIE_RANDOM, noise_mode=E.NOISE_PHILOX,
-                           seed=0, node_capacity=98304, max_plies=128, sample_capacity=G * 72)
+                           seed=0, max_plies=128, sample_capacity=G * 72)
 
     def sync():
         torch.cuda.synchronize()

@@ -105,7 +105,7 @@ typedef struct {
     int32_t temp_max_step, temp_min_step; /* LinearTemperatureScheduler (schedulers.py:20-40) */
     int32_t tie_mode, noise_mode, evaluator;
     uint32_t seed;             /* Philox key word 0; word 1 is the game id */
-    int32_t node_capacity;     /* tree nodes per slot (bump-allocated per game) */
+    int32_t node_capacity;     /* nodes per tree pool (two pools per slot; the kept subtree is compacted at every move) */
     int32_t max_plies;         /* per game, sample staging */
     int64_t sample_capacity;   /* samples the output buffers can hold */
 } az_engine_cfg;
