@@ -21,6 +21,7 @@
 //   k_heads        : policy+value GEMM (N padded to 16) fused with softmax / tanh.
 //   k_mlp          : the 316-parameter TicTacToe MLP, one thread per board.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -137,22 +138,23 @@ AZ_D void store_relu_lds(float *out, int lane, const f32x4 (&acc)[MT][2]) {
 template <int CH, int CW>
 struct TrunkGeom {
     static constexpr int P1 = CH * CW, PW = CW + 2, PH = CH + 2;
-    static constexpr int INP = ((PH * PW + 15) / 16) * 16;  // padded input plane (also the guard band in front of r1)
-    static constexpr int PS1 = PLANE_STRIDE(P1), PS2 = PLANE_STRIDE(P1);
-    static constexpr int H3 = CH - 2, W3 = CW - 2, P3 = H3 * W3, PS3 = PLANE_STRIDE(P3);
+    static constexpr int INP = ((PH * PW + 15) / 16) * 16;  // padded input plane (also the guard band in front of the planes)
+    static constexpr int PS = PLANE_STRIDE(P1);             // one plane stride for every layer's activations
+    static constexpr int H3 = CH - 2, W3 = CW - 2, P3 = H3 * W3;
     static constexpr int H4 = CH - 4, W4 = CW - 4, P4 = H4 * W4;
     static constexpr int MT2 = (P1 + 15) / 16, MT3 = (P3 + 15) / 16, MT4 = (P4 + 15) / 16;
-    static constexpr int WAVE_FLOATS = INP + NCH * (PS1 + PS2);
+    static constexpr int TAIL = 16;  // guard band behind the planes (masked out-of-plane reads of the last channel)
+    static constexpr int WAVE_FLOATS = INP + NCH * PS + TAIL;
     static constexpr int LDS_BYTES = 4 * WAVE_FLOATS * 4;
-    static_assert(PS3 <= PS1, "conv3 output reuses the conv1 region");
-    static_assert(INP >= CW + 1 && NCH * PS2 >= CW + 1, "guard bands around r1 for the masked out-of-plane reads");
+    static_assert(INP >= CW + 1 && TAIL >= CW + 1, "guard bands for the masked out-of-plane reads");
 };
 
-// One wavefront per board; activations never leave the wave's private LDS region.
-//   inp : (CH+2)x(CW+2) zero-padded input plane           r1 : conv1 output [32][PS1], later conv3 output
-//   r2  : conv2 output [32][PS2]
-// 17 KB of LDS per wave -> two 4-wave blocks per CU, i.e. two waves per SIMD hide each other's
-// LDS/VALU phases behind MFMA work.
+// One wavefront per board; activations never leave the wave's private LDS region and every layer writes
+// its output IN PLACE over its input (the outputs wait in the MFMA accumulators until the layer's last
+// LDS read has been consumed):
+//   inp : (CH+2)x(CW+2) zero-padded input plane        act : [32 ch][PS] planes, conv1 -> conv2 -> conv3 outputs
+// 8.8 KB of LDS per wave -> four 4-wave blocks per CU, i.e. four waves per SIMD: the MFMA pipe always has
+// another wave's k-steps to run while one wave is in a load / store / conv1 phase.
 template <int CH, int CW>
 __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, TrunkParams tp, float *__restrict__ feat) {
     using G = TrunkGeom<CH, CW>;
@@ -162,8 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, 
     const int b = blockIdx.x * 4 + wave;
     if (b >= B) return;  // waves are independent: no workgroup barrier below
     float *inp = smem + wave * G::WAVE_FLOATS;
-    float *r1 = inp + G::INP;
-    float *r2 = r1 + NCH * G::PS1;
+    float *act = inp + G::INP;
     for (int i = lane; i < G::INP; i += 64) inp[i] = 0.0f;
     LDS_FENCE();
     for (int p = lane; p < G::P1; p += 64) inp[(p / CW + 1) * G::PW + (p % CW) + 1] = in[(size_t)b * G::P1 + p];
@@ -188,25 +189,26 @@ __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, 
                 acc[mt][1] = MFMA(a, b1, acc[mt][1]);
             }
         }
-        store_relu_lds<G::P1, G::PS1, G::MT2>(r1, lane, acc);
+        store_relu_lds<G::P1, G::PS, G::MT2>(act, lane, acc);
     }
     LDS_FENCE();
     {  // conv2 32->32, pad 1 (othello.py:371)
         f32x4 acc[G::MT2][2];
-        conv_mfma<G::P1, CW, CH, CW, G::PS1, 1, G::MT2>(r1, tp.wf[0], tp.cb[0], lane, acc);
-        store_relu_lds<G::P1, G::PS2, G::MT2>(r2, lane, acc);
+        conv_mfma<G::P1, CW, CH, CW, G::PS, 1, G::MT2>(act, tp.wf[0], tp.cb[0], lane, acc);
+        LDS_FENCE();
+        store_relu_lds<G::P1, G::PS, G::MT2>(act, lane, acc);
     }
     LDS_FENCE();
     {  // conv3 32->32, valid (othello.py:372)
         f32x4 acc[G::MT3][2];
-        conv_mfma<G::P3, G::W3, G::H3, CW, G::PS2, 0, G::MT3>(r2, tp.wf[1], tp.cb[1], lane, acc);
+        conv_mfma<G::P3, G::W3, G::H3, CW, G::PS, 0, G::MT3>(act, tp.wf[1], tp.cb[1], lane, acc);
         LDS_FENCE();
-        store_relu_lds<G::P3, G::PS3, G::MT3>(r1, lane, acc);
+        store_relu_lds<G::P3, G::PS, G::MT3>(act, lane, acc);
     }
     LDS_FENCE();
     {  // conv4 32->32, valid (othello.py:373) -> flattened NCHW features (othello.py:374)
         f32x4 acc[G::MT4][2];
-        conv_mfma<G::P4, G::W4, G::H4, G::W3, G::PS3, 0, G::MT4>(r1, tp.wf[2], tp.cb[2], lane, acc);
+        conv_mfma<G::P4, G::W4, G::H4, G::W3, G::PS, 0, G::MT4>(act, tp.wf[2], tp.cb[2], lane, acc);
         float *fo = feat + (size_t)b * (NCH * G::P4);
 #pragma unroll
         for (int mt = 0; mt < G::MT4; ++mt)
@@ -222,35 +224,53 @@ __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, 
 }
 
 // C[M][N] = act(A[M][K] * Bw[K][N] + bias[N]);  K % 32 == 0, N % BN == 0.
-// LDS double buffer, BK = 32, one barrier per K tile; the next tile's global loads are issued
-// before the current tile's 8 MFMA k-steps and written to the other buffer after them.
-template <int BM, int BN, int WM, int WN, bool RELU>
+// f32 MFMA 32x32x2 (sustains ~150 TFLOP/s from a single in-place accumulator chain on this chip; the
+// 16x16x4 shape cycling over many accumulators measured 10-25 % lower: tools/micro/mfma_peak2.hip).
+// LDS double buffer, BK = 32, one barrier per K tile; the global loads of tile t+2 are issued while
+// tile t is computed (two register staging sets); fragment reads run one k-step ahead of the MFMAs.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef AZ_PROBE  // diagnostic build only (make PROBE=1): per-phase shader-clock stamps of wave 0 of every block
+__device__ unsigned long long az_probe_buf[8192 * 8];
+#define STAMP(var) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP(var)
+#endif
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+template <int BM, int BN, int WM, int WN, bool RELU, int KT>
 __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const float *__restrict__ Bw,
                                               const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
                                               const int *__restrict__ dyn_count) {
     if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
-    if ((int)blockIdx.y * BM >= M) return;  // whole block beyond the rows filled this step (uniform exit)
-    constexpr int BK = 32, WAVES_N = BN / WN, TM = WM / 16, TN = WN / 16;
-    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
-    constexpr int ASTR = BK + 2;   // (2m + kq) mod 32 : conflict-free A-fragment reads
-    constexpr int BSTR = BN + 16;  // (16 kq + n) mod 32 : conflict-free B-fragment reads
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (b and b+8 share an L2), so the
+    // linear id is remapped to give every XCD a contiguous run of row bands.  Speed only.
+    const int nbx = N / BN, nb = nbx * (int)gridDim.y;
+    int bid = (int)blockIdx.y * nbx + (int)blockIdx.x;
+    if (nb % 8 == 0) bid = (bid % 8) * (nb / 8) + bid / 8;
+    const int tile_y = bid / nbx, tile_x = bid % nbx;
+    if (tile_y * BM >= M) return;  // whole block beyond the rows filled this step (uniform exit)
+    constexpr int BK = 32, WAVES_N = BN / WN, TM = WM / 32, TN = WN / 32;
+    static_assert((BM / WM) * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves per block, 32x32 MFMA tiles");
+    constexpr int ASTR = BK + 1;  // (m + k) mod 32 : conflict-free A-fragment reads (32 rows, one k)
+    constexpr int BSTR = BN;      // a B-fragment read is 32 consecutive floats of one k row
     constexpr int A_LD = BM * BK / 4 / 256, B_LD = (BK * BN / 4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     float *As = gsm;                    // [2][BM][ASTR]
-    float *Bs = gsm + 2 * BM * ASTR;    // [2][BK][BSTR]
+    float *Bs = gsm + 2 * BM * ASTR;    // [2][BK][BSTR]   (2*BM*ASTR is a multiple of 4 floats: 16-byte aligned)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
-    f32x4 acc[TM][TN];
+    const int bm0 = tile_y * BM, bn0 = tile_x * BN;
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        float bv = bias[bn0 + wn0 + tn * 16 + (lane & 15)];
+        float bv = bias[bn0 + wn0 + tn * 32 + (lane & 31)];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = (f32x4){bv, bv, bv, bv};
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = bv;
     }
-    // staging registers as named scalars (an indexed array here ends up in scratch)
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0, 0, 0, 0);
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = sa0 = sa1 = sa2 = sa3 = sb0 = sb1 = sb2 = sb3 = make_float4(0, 0, 0, 0);
 #define LD_A(i, r, k0)                                                                    \
     if constexpr ((i) < A_LD) {                                                           \
         int idx = tid + (i) * 256, row = idx / (BK / 4), q = idx % (BK / 4);              \
@@ -270,8 +290,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const
     if constexpr ((i) < A_LD) {                                                           \
         int idx = tid + (i) * 256, row = idx / (BK / 4), q = idx % (BK / 4);              \
         float *d = (as) + row * ASTR + 4 * q;                                             \
-        *reinterpret_cast<float2 *>(d) = make_float2(r.x, r.y);                           \
-        *reinterpret_cast<float2 *>(d + 2) = make_float2(r.z, r.w);                       \
+        d[0] = r.x; d[1] = r.y; d[2] = r.z; d[3] = r.w;                                   \
     }
 #define ST_B(i, r, bs)                                                                    \
     if constexpr ((i) < B_LD) {                                                           \
@@ -281,65 +300,116 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const
             *reinterpret_cast<float4 *>((bs) + kr * BSTR + 4 * c4) = r;                   \
         }                                                                                 \
     }
-#define GEMM_ISSUE(k0) { LD_A(0, ra0, k0) LD_A(1, ra1, k0) LD_A(2, ra2, k0) LD_A(3, ra3, k0) LD_B(0, rb0, k0) LD_B(1, rb1, k0) LD_B(2, rb2, k0) LD_B(3, rb3, k0) }
-#define GEMM_STORE(buf)                                                                   \
+#define GEMM_ISSUE_R(k0) { LD_A(0, ra0, k0) LD_A(1, ra1, k0) LD_A(2, ra2, k0) LD_A(3, ra3, k0) LD_B(0, rb0, k0) LD_B(1, rb1, k0) LD_B(2, rb2, k0) LD_B(3, rb3, k0) }
+#define GEMM_ISSUE_S(k0) { LD_A(0, sa0, k0) LD_A(1, sa1, k0) LD_A(2, sa2, k0) LD_A(3, sa3, k0) LD_B(0, sb0, k0) LD_B(1, sb1, k0) LD_B(2, sb2, k0) LD_B(3, sb3, k0) }
+#define GEMM_STORE_R(buf)                                                                 \
     {                                                                                     \
         float *as_ = As + (buf) * BM * ASTR, *bs_ = Bs + (buf) * BK * BSTR;               \
         ST_A(0, ra0, as_) ST_A(1, ra1, as_) ST_A(2, ra2, as_) ST_A(3, ra3, as_)           \
         ST_B(0, rb0, bs_) ST_B(1, rb1, bs_) ST_B(2, rb2, bs_) ST_B(3, rb3, bs_)           \
     }
-    static_assert(A_LD <= 4 && B_LD <= 4, "staging register budget");
-    GEMM_ISSUE(0)
-    GEMM_STORE(0)
-    __syncthreads();
-    const int T = K / BK;
-    for (int t = 0; t < T; ++t) {
-        const bool more = t + 1 < T;
-        if (more) GEMM_ISSUE((t + 1) * BK)
-        const float *as = As + (t & 1) * BM * ASTR + (wm0 + (lane & 15)) * ASTR + (lane >> 4);
-        const float *bs = Bs + (t & 1) * BK * BSTR + (lane >> 4) * BSTR + wn0 + (lane & 15);
-        float afn[TM], bfn[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) afn[tm] = as[tm * 16 * ASTR];
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) bfn[tn] = bs[tn * 16];
-#pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-            float af[TM], bf[TN];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) af[tm] = afn[tm];
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bf[tn] = bfn[tn];
-            if (ks + 1 < BK / 4) {  // next k-step's fragments are in flight while this one's MFMAs issue
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) afn[tm] = as[tm * 16 * ASTR + (ks + 1) * 4];
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bfn[tn] = bs[(ks + 1) * 4 * BSTR + tn * 16];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA(af[tm], bf[tn], acc[tm][tn]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) GEMM_STORE((t + 1) & 1)
-        __syncthreads();
+#define GEMM_STORE_S(buf)                                                                 \
+    {                                                                                     \
+        float *as_ = As + (buf) * BM * ASTR, *bs_ = Bs + (buf) * BK * BSTR;               \
+        ST_A(0, sa0, as_) ST_A(1, sa1, as_) ST_A(2, sa2, as_) ST_A(3, sa3, as_)           \
+        ST_B(0, sb0, bs_) ST_B(1, sb1, bs_) ST_B(2, sb2, bs_) ST_B(3, sb3, bs_)           \
     }
-#undef GEMM_ISSUE
-#undef GEMM_STORE
+#define FRD 4  /* fragment ring: LDS reads run FRD-1 k-steps ahead of the MFMAs (a 32x32x2 k-step is only 64-128 MFMA cycles) */
+#define GEMM_COMPUTE(buf)                                                                 \
+    {                                                                                     \
+        const float *as = As + (buf) * BM * ASTR + (wm0 + (lane & 31)) * ASTR + (lane >> 5);   \
+        const float *bs = Bs + (buf) * BK * BSTR + (lane >> 5) * BSTR + wn0 + (lane & 31);     \
+        float afr[FRD][TM], bfr[FRD][TN];                                                 \
+        _Pragma("unroll") for (int p = 0; p < FRD - 1; ++p) {                             \
+            _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) afr[p][tm] = as[tm * 32 * ASTR + p * 2];          \
+            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) bfr[p][tn] = bs[p * 2 * BSTR + tn * 32];          \
+        }                                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < BK / 2; ++ks) {                           \
+            if (ks + FRD - 1 < BK / 2) {                                                  \
+                _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) afr[(ks + FRD - 1) % FRD][tm] = as[tm * 32 * ASTR + (ks + FRD - 1) * 2];   \
+                _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) bfr[(ks + FRD - 1) % FRD][tn] = bs[(ks + FRD - 1) * 2 * BSTR + tn * 32];   \
+            }                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+            _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                             \
+                _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA32(afr[ks % FRD][tm], bfr[ks % FRD][tn], acc[tm][tn]); \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+        }                                                                                 \
+    }
+    static_assert(A_LD <= 4 && B_LD <= 4, "staging register budget");
+    // KT > 0: the tile loop is fully unrolled.  hipcc's s_waitcnt insertion is exact only in straight-line code;
+    // around a loop back-edge it drains every outstanding global load at the top of each tile, which
+    // serialises the prefetch with the MFMAs (global latency here is about one tile of MFMA work).
+    const int T = KT > 0 ? KT : K / BK;
+    GEMM_ISSUE_R(0)
+    if (T > 1) GEMM_ISSUE_S(BK)
+    GEMM_STORE_R(0)
+    __syncthreads();
+    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, ph_issue = 0, ph_comp = 0, ph_store = 0, ph_bar = 0, p_begin = 0;
+    (void)p0; (void)p1; (void)p2; (void)p3; (void)p4; (void)ph_issue; (void)ph_comp; (void)ph_store; (void)ph_bar; (void)p_begin;
+    STAMP(p_begin)
+#ifdef AZ_PROBE
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+#define GEMM_PAIR(t)                                                                      \
+    {                                                                                     \
+        STAMP(p0)                                                                         \
+        if ((t) + 2 < T) GEMM_ISSUE_R(((t) + 2) * BK)                                     \
+        STAMP(p1)                                                                         \
+        GEMM_COMPUTE(0)                                                                   \
+        STAMP(p2)                                                                         \
+        if ((t) + 1 < T) GEMM_STORE_S(1)                                                  \
+        STAMP(p3)                                                                         \
+        __syncthreads();                                                                  \
+        STAMP(p4)                                                                         \
+        ph_issue += p1 - p0; ph_comp += p2 - p1; ph_store += p3 - p2; ph_bar += p4 - p3;  \
+        if ((t) + 1 < T) {                                                                \
+            STAMP(p0)                                                                     \
+            if ((t) + 3 < T) GEMM_ISSUE_S(((t) + 3) * BK)                                 \
+            STAMP(p1)                                                                     \
+            GEMM_COMPUTE(1)                                                               \
+            STAMP(p2)                                                                     \
+            if ((t) + 2 < T) GEMM_STORE_R(0)                                              \
+            STAMP(p3)                                                                     \
+            __syncthreads();                                                              \
+            STAMP(p4)                                                                     \
+            ph_issue += p1 - p0; ph_comp += p2 - p1; ph_store += p3 - p2; ph_bar += p4 - p3;  \
+        }                                                                                 \
+    }
+    if constexpr (KT > 0) {
+#pragma unroll
+        for (int t = 0; t < KT; t += 2) GEMM_PAIR(t)
+    } else {
+        for (int t = 0; t < T; t += 2) GEMM_PAIR(t)
+    }
+#undef GEMM_PAIR
+#undef GEMM_ISSUE_R
+#undef GEMM_ISSUE_S
+#undef GEMM_STORE_R
+#undef GEMM_STORE_S
+#undef GEMM_COMPUTE
+#undef FRD
 #undef LD_A
 #undef LD_B
 #undef ST_A
 #undef ST_B
+#ifdef AZ_PROBE
+    if (tid == 0 && bid < 8192) {
+        unsigned long long p_end = 0;
+        STAMP(p_end)
+        unsigned long long *o = az_probe_buf + (size_t)bid * 8;
+        o[0] = ph_issue; o[1] = ph_comp; o[2] = ph_store; o[3] = ph_bar; o[4] = p_end - p_begin; o[5] = p_begin; o[6] = p_end;
+        o[7] = __builtin_amdgcn_s_memrealtime() - rt_begin;  // 100 MHz ticks
+    }
+#endif
+    // C/D layout of 32x32x2: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int row = bm0 + wm0 + tm * 16 + (lane >> 4) * 4 + r;
-                int col = bn0 + wn0 + tn * 16 + (lane & 15);
+            for (int r = 0; r < 16; ++r) {
+                int row = bm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                int col = bn0 + wn0 + tn * 32 + (lane & 31);
                 float v = acc[tm][tn][r];
                 if (RELU) v = v > 0.0f ? v : 0.0f;
                 if (row < M) C[(size_t)row * N + col] = v;
@@ -347,7 +417,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const
 }
 
 template <int BM, int BN>
-constexpr int gemm_lds_bytes() { return 4 * (2 * BM * (32 + 2) + 2 * 32 * (BN + 16)); }
+constexpr int gemm_lds_bytes() { return 4 * (2 * BM * (32 + 1) + 2 * 32 * BN); }
 
 // policy + value heads (othello.py:379-382, base.py:355): logits = h2 * Wh + bh with
 // Wh = [fc_probs | fc_value | 0-pad] of width NH = 16*NT; then softmax over the first A columns
@@ -717,27 +787,47 @@ template <int CH, int CW>
 static int launch_trunk(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
     using G = TrunkGeom<CH, CW>;
     static bool attr_set = false;
+    static int lds_bytes = G::LDS_BYTES;
     if (!attr_set) {
-        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk<CH, CW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        // resident blocks per CU = 160 KB / lds_bytes.  Measured on MI355X (4096 boards): 3 or 2 blocks per CU
+        // 88 us, 4 blocks 94 us, 1 block 92 us -> pad the request to 3; AZ_TRUNK_BLOCKS_PER_CU overrides.
+        const char *e = getenv("AZ_TRUNK_BLOCKS_PER_CU");
+        int want = e ? atoi(e) : 3;
+        if (want >= 1 && want <= 8 && 160 * 1024 / want > G::LDS_BYTES) lds_bytes = (160 * 1024 / want) & ~15;
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk<CH, CW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_trunk<CH, CW>), dim3((B + 3) / 4), dim3(256), G::LDS_BYTES, st, in, B, dyn, n->tp, n->feat);
+    hipLaunchKernelGGL((k_trunk<CH, CW>), dim3((B + 3) / 4), dim3(256), lds_bytes, st, in, B, dyn, n->tp, n->feat);
     return AZ_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
-static int gemm_go(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int KT>
+static int gemm_launch(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
     constexpr int lds = gemm_lds_bytes<BM, BN>();
     static bool attr_set = false;
     if (!attr_set) {
-        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<BM, BN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<BM, BN, WM, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<BM, BN, WM, WN, true, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<BM, BN, WM, WN, false, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     dim3 grid(N / BN, (M + BM - 1) / BM);
-    if (relu) hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
-    else hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+    if (relu) hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true, KT>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+    else hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false, KT>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
     return AZ_OK;
+}
+
+// K of the networks' dense layers gets an unrolled instantiation: 512 / 1024 (Othello 8x8), 128 (Othello 6x6),
+// 192 / 64 (Connect4); anything else runs the runtime loop
+template <int BM, int BN, int WM, int WN>
+static int gemm_go(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
+    switch (K) {
+        case 1024: return gemm_launch<BM, BN, WM, WN, 32>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+        case 512: return gemm_launch<BM, BN, WM, WN, 16>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+        case 192: return gemm_launch<BM, BN, WM, WN, 6>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+        case 128: return gemm_launch<BM, BN, WM, WN, 4>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+        case 64: return gemm_launch<BM, BN, WM, WN, 2>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+        default: return gemm_launch<BM, BN, WM, WN, 0>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+    }
 }
 
 static int launch_gemm(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
@@ -838,3 +928,10 @@ extern "C" int az_net_time_stage(az_net *n, int stage, int B, int iters, void *s
     (void)hipFree(in); (void)hipFree(pr); (void)hipFree(va);
     return rc;
 }
+
+#ifdef AZ_PROBE
+extern "C" int az_debug_read_probe(unsigned long long *h_out, int n_words) {
+    AZ_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(az_probe_buf), sizeof(unsigned long long) * (size_t)n_words));
+    return AZ_OK;
+}
+#endif
