@@ -125,9 +125,9 @@ def main():
         dom = int(np.argmax(ms))
         ach = fl[dom] * G / (ms[dom] * 1e-3) / 1e12
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(STAGE_NAMES[dom].split()[0] + ("_" + STAGE_NAMES[dom].split()[1] if dom in (1, 2) else ""))
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tfile) and G == 4096:
+            traffic = json.load(open(tfile)).get(["k_trunk", "k_gemm_fc1", "k_gemm_fc2", "k_heads"][dom])
         out["roofline"] = {"bound": "mfma", "kernel": STAGE_NAMES[dom], "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                            "launch_ms": ms[dom], "algorithmic_flops_per_launch": fl[dom] * G,
