@@ -633,6 +633,39 @@ __global__ __launch_bounds__(256) void k_reroot(EngDev E) {
     }
 }
 
+// Board.play_move + MCT.change_root (mcts.py:118-125) for a move chosen OUTSIDE the engine (arena opponent,
+// human): re-root at the child if the root's children are materialised and hold the action, otherwise start
+// a fresh root.  status[g] = 0 or AZ_EILLEGAL (reference: ValueError, board untouched).  One thread per slot.
+__global__ void k_apply_moves(EngDev E, const int *actions, int n, int *status) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n || g >= E.G) return;
+    if (!E.active[g]) { status[g] = AZ_ESTATE; return; }
+    const GameDesc &gd = E.gd;
+    Node *pool = pool_of(E, g);
+    BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
+    const int a = actions[g];
+    u64 bits = az_legal_bits(gd, b, b.player);
+    bool ok = false;
+    if (a >= 0 && a < gd.A) {
+        if (gd.game == AZ_OTHELLO && a == gd.A - 1) ok = (bits == 0);
+        else ok = (bits >> az_action_to_bit(gd, a)) & 1ULL;
+    }
+    if (!ok) { status[g] = AZ_EILLEGAL; return; }
+    const int root = E.root[g];
+    int chosen = -1;
+    if (pool[root].flags & F_EXPANDED)
+        for (int i = 0; i < pool[root].nch; ++i)
+            if (pool[pool[root].first + i].act == a) chosen = pool[root].first + i;
+    if (chosen < 0) { chosen = 0; store_node(pool, fresh_node(0, -1, 0.0, 0)); }  // mcts.py:124-125
+    pool[chosen].parent = -1;
+    az_play(gd, b, a);
+    E.root_p1[g] = b.p1; E.root_m1[g] = b.m1; E.root_player[g] = (int8_t)b.player;
+    E.root[g] = chosen;
+    E.ply[g] = E.ply[g] + 1;
+    E.leaf_status[g] = LS_NONE;
+    status[g] = AZ_OK;
+}
+
 // closed-form fake network (tests): reads the canonical board back from nn_in
 __global__ void k_fakenet(EngDev E, const int *cnt) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -919,4 +952,23 @@ extern "C" int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_ac
         if (h_P) h_P[i] = ch[i].P;
     }
     return AZ_OK;
+}
+
+extern "C" int az_engine_play(az_engine *e, const int32_t *h_actions, int32_t n, int32_t *h_status) {
+    AZ_REQUIRE(e && h_actions && h_status, AZ_EINVAL, "null argument");
+    EngDev &d = e->d;
+    AZ_REQUIRE(n > 0 && n <= d.G, AZ_EINVAL, "n must be in [1, n_slots]");
+    int *d_act = nullptr, *d_st = nullptr;
+    AZ_HIP(hipMalloc((void **)&d_act, sizeof(int) * n));
+    AZ_HIP(hipMalloc((void **)&d_st, sizeof(int) * n));
+    AZ_HIP(hipMemcpyAsync(d_act, h_actions, sizeof(int) * n, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_apply_moves, grid_for(n, TB), dim3(TB), 0, e->stream, d, d_act, (int)n, d_st);
+    hipLaunchKernelGGL(k_reroot, dim3((unsigned)((d.G + GPB - 1) / GPB)), dim3(256), 0, e->stream, d);
+    AZ_HIP(hipMemcpyAsync(h_status, d_st, sizeof(int) * n, hipMemcpyDeviceToHost, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    (void)hipFree(d_act); (void)hipFree(d_st);
+    for (int i = 0; i < n; ++i)
+        if (h_status[i] == AZ_EILLEGAL) { az_set_error("Illegal move %d for slot %d", h_actions[i], i); return AZ_EILLEGAL; }
+    AZ_TRY(fetch_counters(e));
+    return check_err(e);
 }

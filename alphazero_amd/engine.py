@@ -190,6 +190,12 @@ class SelfPlayEngine:
     def advance(self):
         check(lib().az_engine_advance(self.h))
 
+    def play(self, actions):
+        """Board.play_move + MCT.change_root with externally chosen moves for slots 0..len(actions)-1"""
+        a = np.ascontiguousarray(actions, np.int32)
+        st = np.zeros(len(a), np.int32)
+        check(lib().az_engine_play(self.h, a.ctypes.data, len(a), st.ctypes.data))
+
     def root_children(self, slot):
         a = np.zeros(65, np.int32); n = np.zeros(65, np.int32); q = np.zeros(65, np.float64); p = np.zeros(65, np.float64)
         k, rn = C.c_int32(), C.c_int32()

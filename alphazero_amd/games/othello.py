@@ -1,9 +1,10 @@
-"""Othello plugin: OthelloConfig, OthelloNet (othello.py:17-47, 306-450).  OthelloBoard: see boards.py."""
+"""Othello plugin: OthelloConfig, OthelloBoard, OthelloNet (othello.py:17-450)."""
 from dataclasses import dataclass
 
 import numpy as np
 
-from ..base import Config
+from ..base import Board, Config
+from . import _bitrules as R
 from ._convnet import ConvPolicyValueNet, uniform_or_normalised
 
 
@@ -74,3 +75,105 @@ class OthelloNet(ConvPolicyValueNet):
     def rotate_neural_output(self, neural_output, angle):
         board, tail = self._board_part(neural_output)
         return np.concatenate([np.rot90(board, k=angle // 90).reshape(-1), tail]).astype(neural_output.dtype)
+
+
+class OthelloBoard(Board):
+    """n x n Othello (othello.py:50-229).  `grid` holds 1 (black, moves first), -1 (white), 0; every query is
+    answered from the current `grid`/`player`, so callers may edit them like they do with the reference."""
+    CONFIG = OthelloConfig
+
+    def __init__(self, n=None, grid=None, player=1, display_dir=None, display_mode=None, config=None):
+        super().__init__(display_dir=display_dir, display_mode=display_mode)
+        self.game = "othello"
+        if config is not None:
+            self.n = config.board_size
+            self.reset()
+        else:
+            self.n = n
+            self.grid = grid if grid is not None else self._start_grid()
+            self.player = player
+            self.pass_move = self.get_board_shape()
+            self.max_moves = self.n * self.n - 4
+        if self.n % 2 != 0:
+            raise ValueError(f"Board size must be even but got n={self.n}")
+
+    def _start_grid(self):
+        g = np.zeros((self.n, self.n))
+        h = self.n // 2
+        g[h - 1][h - 1] = g[h][h] = 1
+        g[h - 1][h] = g[h][h - 1] = -1
+        return g
+
+    def reset(self):
+        self.grid = self._start_grid()
+        self.player = 1
+        self.pass_move = self.get_board_shape()
+        self.max_moves = self.n * self.n - 4
+
+    def __str__(self):
+        return f"{type(self).__name__}{self.n}"
+
+    def clone(self):
+        return OthelloBoard(n=self.n, grid=self.grid.copy(), player=self.player, display_dir=self.display_dir)
+
+    def get_board_shape(self):
+        return self.grid.shape
+
+    def get_n_cells(self):
+        return np.prod(self.get_board_shape())
+
+    def get_action_size(self):
+        return self.n * self.n + 1
+
+    def get_score(self):
+        return np.sum(self.player * self.grid).astype(int)
+
+    def _sides(self, player):
+        player = player if player in (-1, 1) else self.player
+        p1, m1 = R.pack(self.grid)
+        return (p1, m1) if player > 0 else (m1, p1)
+
+    def _legal_bits(self, player=None):
+        own, opp = self._sides(player)
+        return R.othello_legal(own, opp, R.valid_mask(self.n, self.n))
+
+    def is_legal_move(self, move, player=None):
+        legal = self._legal_bits(player)
+        if tuple(move) == tuple(self.pass_move):
+            return legal == 0
+        r, c = move
+        if not (0 <= r < self.n and 0 <= c < self.n):
+            return False
+        return bool((legal >> (r * 8 + c)) & 1)
+
+    def get_moves(self, player=None):
+        """legal cells in row-major order, or [pass_move] (the reference returns them in set order)"""
+        moves = [(b >> 3, b & 7) for b in R.bits(self._legal_bits(player))]
+        return moves if moves else [self.pass_move]
+
+    def get_random_move(self, player=None):
+        moves = self.get_moves(player)
+        return moves[np.random.choice(len(moves))]
+
+    def play_move(self, move):
+        if not self.is_legal_move(move):
+            raise ValueError(f"Illegal move {move} for player {self.player}")
+        if tuple(move) == (self.n, self.n):
+            self.player = -self.player
+            return
+        own, opp = self._sides(None)
+        mv = 1 << (move[0] * 8 + move[1])
+        for b in R.bits(R.othello_flips(own, opp, mv) | mv):
+            self.grid[b >> 3][b & 7] = self.player
+        self.player = -self.player
+
+    def is_game_over(self):
+        return self._legal_bits(1) == 0 and self._legal_bits(-1) == 0
+
+    def get_winner(self):
+        if not self.is_game_over():
+            raise ValueError("Game is not over yet...")
+        score = self.get_score()
+        if score == 0:
+            return 0
+        return self.player if score > 0 else -self.player

@@ -1,4 +1,4 @@
-"""TicTacToe plugin: TicTacToeConfig, TicTacToeNet (tictactoe.py:17-47, 262-367).  Board: see boards.py."""
+"""TicTacToe plugin: TicTacToeConfig, TicTacToeBoard, TicTacToeNet (tictactoe.py:17-367)."""
 from dataclasses import dataclass
 
 import numpy as np
@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..base import Config, PolicyValueNetwork
+from ..base import Board, Config, PolicyValueNetwork
 from ._convnet import uniform_or_normalised
 
 
@@ -82,3 +82,76 @@ class TicTacToeNet(PolicyValueNetwork):
 
     def rotate_neural_output(self, neural_output, angle):
         return np.rot90(self._check(neural_output), k=angle // 90).flatten()
+
+
+class TicTacToeBoard(Board):
+    """3 x 3 TicTacToe (tictactoe.py:50-184)."""
+    CONFIG = TicTacToeConfig
+
+    def __init__(self, grid=None, player=1, display_dir=None, display_mode=None, config=None):
+        super().__init__(display_dir=display_dir, display_mode=display_mode)
+        self.game = "tictactoe"
+        if config is not None:
+            self.reset()
+        else:
+            self.grid = grid if grid is not None else np.zeros((3, 3))
+            self.player = player
+            self.max_moves = 9
+
+    def reset(self):
+        self.grid = np.zeros((3, 3))
+        self.player = 1
+        self.max_moves = 9
+
+    def clone(self):
+        return TicTacToeBoard(grid=self.grid.copy(), player=self.player, display_dir=self.display_dir)
+
+    def get_board_shape(self):
+        return self.grid.shape
+
+    def get_n_cells(self):
+        return np.prod(self.grid.shape)
+
+    def get_action_size(self):
+        return self.get_n_cells()
+
+    @staticmethod
+    def _alignments(a):
+        return np.concatenate([a.sum(axis=1), a.sum(axis=0), [np.trace(a), np.trace(np.fliplr(a))]])
+
+    def get_alignments_sums(self):
+        return self._alignments(self.grid)
+
+    def get_nb_free_cells_on_alignments(self, player=None):
+        return self._alignments((self.grid == 0).astype(int))
+
+    def get_score(self):
+        """inf when the side to move can complete a line at once, else 0 (tictactoe.py:119-126)"""
+        mine = self.player * self.get_alignments_sums()
+        has_room = (self.get_nb_free_cells_on_alignments() > 0).astype(int)
+        return float("inf") if 2 in mine * has_room else 0
+
+    def is_legal_move(self, move, player=None):
+        return bool(0 <= move[0] < 3 and 0 <= move[1] < 3 and self.grid[move[0]][move[1]] == 0)
+
+    def get_moves(self, player=None):
+        return [(cell[0], cell[1]) for cell in np.vstack(np.where(self.grid == 0)).T]
+
+    def get_random_move(self, player=None):
+        moves = self.get_moves(player)
+        return moves[np.random.choice(len(moves))]
+
+    def play_move(self, move):
+        if not self.is_legal_move(move):
+            raise ValueError(f"Illegal move {move} for player {self.player}")
+        self.grid[move[0]][move[1]] = self.player
+        self.player = -self.player
+
+    def is_game_over(self):
+        return bool(3 in np.abs(self.get_alignments_sums()) or np.all(self.grid != 0))
+
+    def get_winner(self):
+        if not self.is_game_over():
+            raise ValueError("Game is not over yet...")
+        sums = self.get_alignments_sums()
+        return 1 if 3 in sums else (-1 if -3 in sums else 0)

@@ -1,0 +1,266 @@
+"""AlphaZeroTrainer with the reference's interface (trainer.py:30-572).  self_play runs on the HIP engine:
+all episodes of an iteration are played concurrently in lock-step on the GPU instead of one after the other.
+Timers, plotting and HF-hub pushes are out of scope."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import base
+from .arena import Arena
+from .base import DataTransf, dotdict
+from .games.registers import BOARDS_REGISTER, CONFIGS_REGISTER, DATA_AUGMENT_STRATEGIES, NETWORKS_REGISTER
+from .players import PLAYERS_REGISTER, PLAYERS_SET, AlphaZeroPlayer
+from .schedulers import TEMP_SCHEDULERS
+
+
+class Sample:
+    """one training example (trainer.py:30-118)"""
+
+    def __init__(self, state, pi, player, outcome=None, episode_idx=None, move_idx=None, transformation=None):
+        self.state, self.pi, self.player, self.outcome = state, pi, player, outcome
+        self.episode_idx, self.move_idx, self.transformation = episode_idx, move_idx, transformation
+
+    def normalize(self):
+        self.state = self.state * self.player
+        self.outcome = self.outcome * self.player
+        self.player = 1
+
+    def _twin(self, state, pi, mode):
+        tag = mode.value if self.transformation is None else f"{self.transformation}+{mode.value}"
+        return Sample(state=state, pi=pi, player=self.player, outcome=self.outcome, episode_idx=self.episode_idx,
+                      move_idx=self.move_idx, transformation=tag)
+
+    def create_reflection_twin(self, reflection, mode):
+        if mode not in (DataTransf.REFLECT_H, DataTransf.REFLECT_V):
+            raise ValueError(f"Reflection mode must be either {DataTransf.REFLECT_H} or {DataTransf.REFLECT_V}.")
+        axis = 1 if mode == DataTransf.REFLECT_H else 0
+        return self._twin(np.flip(self.state.copy(), axis=axis), reflection(self.pi.copy(), axis=axis), mode)
+
+    def create_rotation_twin(self, rotation, mode):
+        angles = {DataTransf.ROTATE_90: 90, DataTransf.ROTATE_180: 180, DataTransf.ROTATE_270: 270}
+        if mode not in angles:
+            raise ValueError(f"Rotation mode must be either {DataTransf.ROTATE_90}, {DataTransf.ROTATE_180} or {DataTransf.ROTATE_270}.")
+        return self._twin(np.rot90(self.state.copy(), k=angles[mode] // 90), rotation(self.pi.copy(), angle=angles[mode]), mode)
+
+
+def augment(memory, nn, strategy):
+    """symmetry augmentation of samples with move_idx >= 2 (trainer.py:275-284)"""
+    extra = []
+    for s in memory:
+        if s.move_idx >= 2:
+            mirrored = s.create_reflection_twin(nn.reflect_neural_output, mode=strategy.reflection)
+            extra.append(mirrored)
+            for rot in strategy.rotations:
+                extra.append(s.create_rotation_twin(nn.rotate_neural_output, mode=rot))
+                extra.append(mirrored.create_rotation_twin(nn.rotate_neural_output, mode=rot))
+    return extra
+
+
+class AlphaZeroTrainer:
+    DEFAULT_EXP_NAME = "alphazero-undefined"
+
+    def __init__(self, verbose=False, engine_slots=4096, seed=0):
+        self.game = self.config = self.board = self.nn = self.nn_twin = None
+        self.az_player = self.temp_scheduler = self.data_augment_strategy = None
+        self.memory = self.loss_values = self.eval_results = None
+        self.verbose = verbose
+        self.engine_slots, self.seed = engine_slots, seed
+        self._engine = self._hipnet = None
+        self.device_samples = None  # the last self-play wave as CUDA tensors (state, pi, z, meta, visits)
+
+    def __str__(self):
+        return f"{type(self).__name__}{self.game.capitalize()}" if self.game is not None else type(self).__name__
+
+    def print(self, log):
+        if self.verbose:
+            print(log)
+
+    @staticmethod
+    def load_config_from_json(game, json_config_file):
+        if json_config_file is None:
+            return CONFIGS_REGISTER[game]()
+        with open(json_config_file) as f:
+            cfg = dotdict(json.load(f))
+        return CONFIGS_REGISTER[cfg.game](**cfg)
+
+    # ------------------------------------------------------------------ self-play on the engine
+    def _shape(self):
+        from .engine import game_shape
+        c = self.config
+        return game_shape(self.game, getattr(c, "board_size", None), getattr(c, "board_width", 7), getattr(c, "board_height", 6))
+
+    def _ensure_engine(self):
+        from .engine import SelfPlayEngine
+        gid, H, W, A = self._shape()
+        c = self.config
+        if c.simulations is None:
+            raise ValueError("the batched engine needs config.simulations (compute_time-bounded search is host-only)")
+        slots = max(1, min(self.engine_slots, c.episodes))
+        if self._hipnet is None:
+            self._hipnet = self.nn.to_hip(max_batch=slots)
+        else:
+            self._hipnet.load_state_dict(self.nn.state_dict())
+        if self._engine is None:
+            if c.temp_scheduler_type == "constant":
+                tmax, tmin = -1, 0  # always greedy (schedulers.py:15-17)
+            else:
+                tmax, tmin = c.temp_max_step, c.temp_min_step
+            plies = 2 * H * W if gid == 0 else H * W + 1
+            self._engine = SelfPlayEngine(gid, H, W, n_slots=slots, n_sim=c.simulations, net=self._hipnet,
+                                          dirichlet_alpha=c.dirichlet_alpha, dirichlet_epsilon=c.dirichlet_epsilon,
+                                          temp_max_step=tmax, temp_min_step=tmin, seed=self.seed, max_plies=plies,
+                                          sample_capacity=c.episodes * plies)
+        return self._engine
+
+    def self_play(self, iter_idx):
+        """trainer.py:215-286: fills self.memory with normalised samples (+ symmetry twins)"""
+        eng = self._ensure_engine()
+        n = self.config.episodes
+        smp = eng.run(n, first_game_id=iter_idx * n)
+        self.device_samples = smp
+        meta = smp["meta"].cpu().numpy()
+        order = np.lexsort((meta[:, 1], meta[:, 0]))
+        state = smp["state"].cpu().numpy()[order].astype(np.float64)
+        pi = smp["pi"].cpu().numpy()[order].astype(np.float64)
+        z = smp["z"].cpu().numpy()[order]
+        meta = meta[order]
+        first = iter_idx * n
+        self.memory = [Sample(state=state[i], pi=pi[i], player=1, outcome=int(z[i]), episode_idx=int(meta[i, 0]) - first,
+                              move_idx=int(meta[i, 1])) for i in range(len(z))]
+        if self.config.data_augmentation:
+            self.memory += augment(self.memory, self.nn, self.data_augment_strategy)
+        self.print(f"Total number of samples: {len(self.memory)}")
+
+    # ------------------------------------------------------------------ optimisation (trainer.py:288-387)
+    def _batch_generator(self, n_batches):
+        idx = np.arange(len(self.memory))
+        np.random.shuffle(idx)
+        bs = self.config.batch_size
+        shape = self.memory[0].state.shape
+        for rows in idx[: n_batches * bs].reshape(n_batches, bs):
+            x = np.stack([self.memory[i].state for i in rows]).reshape((bs,) + shape)
+            pi = np.stack([self.memory[i].pi for i in rows])
+            z = np.array([[self.memory[i].outcome] for i in rows], dtype=np.float64)
+            dev = self.config.device
+            yield (torch.tensor(x, dtype=torch.float32, device=dev), torch.tensor(pi, dtype=torch.float32, device=dev),
+                   torch.tensor(z, dtype=torch.float32, device=dev))
+
+    def optimize_network(self, iter_idx):
+        self.nn_twin = self.nn.clone()
+        self.nn_twin.train()
+        opt = torch.optim.SGD(self.nn_twin.parameters(), lr=self.config.learning_rate, momentum=0.9, weight_decay=0.0001)
+        sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+        self.loss_values[iter_idx] = {}
+        bs = self.config.batch_size
+        for epoch in range(self.config.epochs):
+            n_batches = len(self.memory) // bs
+            if n_batches == 0:
+                raise ValueError(f"Too few samples in the memory ({len(self.memory)}) to create a batch with batch_size = {bs}")
+            pi_losses, v_losses = [], []
+            for x, pi, z in self._batch_generator(n_batches):
+                opt.zero_grad()
+                log_p, v = self.nn_twin(x)
+                loss_pi = -torch.sum(pi * log_p) / bs
+                loss_v = torch.sum((v - z) ** 2) / bs
+                (loss_pi + loss_v).backward()
+                opt.step()
+                pi_losses.append(loss_pi.cpu().item())
+                v_losses.append(loss_v.cpu().item())
+            self.loss_values[iter_idx][epoch] = {"pi": pi_losses, "v": v_losses}
+            sched.step()
+
+    def update_network(self, iter_idx):
+        self.nn = self.nn_twin.clone()
+        self.nn_twin = None
+        self.az_player.mct.nn = self.nn
+
+    # ------------------------------------------------------------------ evaluation (trainer.py:389-446)
+    def _init_evaluator(self):
+        if not self.config.do_eval:
+            return
+        opp = self.config.eval_opponent
+        if opp not in PLAYERS_SET:
+            raise ValueError(f"Opponent player '{opp}' not found in the players register.")
+        if opp == "human":
+            raise ValueError("Evaluation against a HumanPlayer during training is not allowed.")
+        if opp == "alphazero":
+            raise ValueError("Evaluation against another AlphaZeroPlayer during training is not yet implemented.")
+        self.eval_results = {"eval_opponent": opp, "eval_episodes": self.config.eval_episodes, "results": {}}
+
+    def evaluate(self, iter_idx):
+        if not self.config.do_eval:
+            return
+        kwargs = {"n_sim": self.config.simulations} if self.config.eval_opponent == "mcts" else {}
+        eval_player = AlphaZeroPlayer(n_sim=self.config.simulations, compute_time=self.config.compute_time, nn=self.nn)
+        opponent = PLAYERS_REGISTER[self.config.eval_opponent](**kwargs)
+        arena = Arena(player1=eval_player, player2=opponent, board=BOARDS_REGISTER[self.game](config=self.config))
+        stats = arena.play_games(n_rounds=self.config.eval_episodes, return_stats=True)
+        for key in ("player1", "player2", "draw"):
+            stats.pop(key, None)
+        self.eval_results["results"][iter_idx] = {k: dict(v) for k, v in stats.items()}
+        self.eval_results["player1"], self.eval_results["player2"] = f"{eval_player}", f"{opponent}"
+
+    # ------------------------------------------------------------------ persistence (trainer.py:448-473)
+    def _model_dir(self, model_name, path):
+        path = os.path.join(base.DEFAULT_MODELS_PATH, model_name) if path is None else path
+        os.makedirs(path, exist_ok=True)
+        return path
+
+    def save_player_pt(self, model_name, path=None):
+        self.nn.save_model(model_name, self._model_dir(model_name, path), verbose=False)
+
+    def save_player_config(self, model_name, path=None):
+        with open(os.path.join(self._model_dir(model_name, path), "config.json"), "w") as f:
+            json.dump(self.config.to_dict(), f, indent=4)
+
+    def save_training_stats(self, model_name, path=None):
+        path = self._model_dir(model_name, path)
+        with open(os.path.join(path, "loss.json"), "w") as f:
+            json.dump(self.loss_values, f, indent=4)
+        if self.config.do_eval:
+            with open(os.path.join(path, "eval.json"), "w") as f:
+                json.dump(self.eval_results, f, indent=4)
+
+    # ------------------------------------------------------------------ policy iteration (trainer.py:475-572)
+    def train(self, game=None, experiment_name=None, json_config_file=None, plot=False, verbose=None):
+        if game is None and json_config_file is None:
+            raise ValueError("The name of the game or a JSON configuration file must be provided to launch a training.")
+        self.config = self.load_config_from_json(game, json_config_file)
+        self.game = game if game is not None else self.config.game
+        if self.game != self.config.game:
+            raise ValueError(f"Game '{game}' and game '{self.config.game}' in the configuration file do not match.")
+        experiment_name = experiment_name or self.DEFAULT_EXP_NAME
+        self.verbose = verbose if verbose is not None else self.verbose
+        c = self.config
+        c.save_checkpoints = c.save_checkpoints or c.push_checkpoints
+        c.push = c.push or c.push_checkpoints
+        c.save = c.save or c.push or c.save_checkpoints
+        self.setup()
+        self.save_player_config(experiment_name)
+        for it in range(c.iterations):
+            self.print(f"\n----- Iteration {it+1}/{c.iterations} -----")
+            self.self_play(it)
+            self.optimize_network(it)
+            self.update_network(it)
+            self.evaluate(it)
+            self.save_training_stats(experiment_name)
+            if c.save_checkpoints:
+                self.save_player_pt(f"{experiment_name}-chkpt-{it+1}",
+                                    path=os.path.join(base.DEFAULT_MODELS_PATH, experiment_name, "checkpoints"))
+        if c.save:
+            self.save_player_pt(experiment_name)
+
+    def setup(self):
+        """objects train() creates before the loop (trainer.py:500-518); needs self.game and self.config"""
+        c = self.config
+        self.board = BOARDS_REGISTER[self.game](config=c)
+        self.nn = NETWORKS_REGISTER[self.game](config=c)
+        self.az_player = AlphaZeroPlayer(n_sim=c.simulations, compute_time=c.compute_time, nn=self.nn,
+                                         dirichlet_alpha=c.dirichlet_alpha, dirichlet_epsilon=c.dirichlet_epsilon)
+        self.temp_scheduler = TEMP_SCHEDULERS[c.temp_scheduler_type](temp_max_step=c.temp_max_step, temp_min_step=c.temp_min_step,
+                                                                     max_steps=self.board.max_moves)
+        self.data_augment_strategy = DATA_AUGMENT_STRATEGIES[self.game] if c.data_augmentation else None
+        self._init_evaluator()
+        self.loss_values = {}

@@ -134,6 +134,10 @@ int az_engine_set_roots(az_engine *e, const int8_t *h_grids, const int8_t *h_pla
 int az_engine_search(az_engine *e, int32_t n_sim);     /* MCT.search on every active slot */
 /* MCT.get_action_probs + sampled move + Board.play_move + MCT.change_root (+ sample record) */
 int az_engine_advance(az_engine *e);
+/* Board.play_move + MCT.change_root (mcts.py:118-125) with externally chosen moves for slots 0..n-1 (arena
+ * opponent / human): re-roots at the child when the tree holds it, else starts a fresh root.  AZ_EILLEGAL and
+ * h_status[i] = AZ_EILLEGAL for an illegal move (reference: ValueError), boards untouched for those slots. */
+int az_engine_play(az_engine *e, const int32_t *h_actions, int32_t n, int32_t *h_status);
 /* root statistics of one slot to HOST arrays (capacity AZ_MAX 65): actions, N, Q, P */
 int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_actions, int32_t *h_N, double *h_Q,
                             double *h_P, int32_t *count, int32_t *root_N);

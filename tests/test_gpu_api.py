@@ -1,0 +1,116 @@
+"""GPU: the reference-compatible Python surface (MCT, AlphaZeroPlayer, Arena, AlphaZeroTrainer) driving the HIP engine."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from alphazero_amd import base
+from alphazero_amd.arena import Arena
+from alphazero_amd.games.othello import OthelloBoard, OthelloConfig, OthelloNet
+from alphazero_amd.games.tictactoe import TicTacToeConfig
+from alphazero_amd.mcts import MCT
+from alphazero_amd.players import AlphaZeroPlayer, GreedyPlayer, RandomPlayer
+from alphazero_amd.trainer import AlphaZeroTrainer
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_net(net, n):
+    return O.ConvNet(O.OTHELLO, n, n, {k: v.numpy() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")})
+
+
+def test_mct_neural_equals_oracle_tree():
+    torch.manual_seed(3)
+    net = OthelloNet(n=6).eval()
+    board = OthelloBoard(n=6)
+    np.random.seed(1)
+    gid = int(np.random.randint(0, 2**31 - 1))
+    np.random.seed(1)
+    mct = MCT(eval_method="neural", nn=net, dirichlet_alpha=0.03, dirichlet_epsilon=0.25, seed=5)
+    mct.search(board, n_sim=60)
+    probs, visits = mct.get_action_probs(board, temp=1)
+    ref = O.MCT(("conv", oracle_net(net, 6)), alpha=0.03, eps=0.25, tie_mode=O.TIE_RANDOM, noise_mode=O.NOISE_PHILOX, seed=5, game_id=gid)
+    ob = O.new_board(O.OTHELLO, 6, 6)
+    ref.search(ob, 60)
+    a, N, Q, P = ref.root_children()
+    assert visits == {(int(x) // 6, int(x) % 6): int(n) for x, n in zip(a, N)}
+    assert sum(visits.values()) == 60 and abs(sum(probs.values()) - 1) < 1e-12
+    pri = mct.get_prior_probs()
+    assert np.allclose([pri[(int(x) // 6, int(x) % 6)] for x in a], P, atol=0, rtol=0)
+    # tree reuse through change_root, then a move the tree does not hold (fresh root, mcts.py:124-125)
+    move = max(visits, key=visits.get)
+    mct.change_root(move)
+    board.play_move(move)
+    ref.change_root(move[0] * 6 + move[1]); O.lib().orc_play(O.C.byref(ob), move[0] * 6 + move[1]); ref.set_ply(1)
+    mct.search(board, n_sim=40); ref.search(ob, 40)
+    a, N, Q, P = ref.root_children()
+    assert mct.get_action_probs(board, 0)[1] == {(int(x) // 6, int(x) % 6): int(n) for x, n in zip(a, N)}
+    with pytest.raises(ValueError):
+        mct.change_root((0, 0))  # illegal move
+    with pytest.raises(ValueError):
+        MCT().nn = net  # setting a network on a rollout tree (mcts.py:81-82)
+
+
+def test_arena_alphazero_vs_baselines():
+    torch.manual_seed(0)
+    net = OthelloNet(n=6).eval()
+    np.random.seed(2)
+    az = AlphaZeroPlayer(n_sim=20, nn=net)
+    stats = Arena(az, RandomPlayer(), OthelloBoard(n=6)).play_games(4, return_stats=True)
+    assert len(stats["player1"]) + len(stats["player2"]) + stats["draw"] == 4
+    assert sum(stats["player1_starts"].values()) == 2 and sum(stats["player2_starts"].values()) == 2
+    res = Arena(GreedyPlayer(), az, OthelloBoard(n=6)).play_game(return_results=True)
+    assert res["winner"] in (0, 1, 2)
+    b = OthelloBoard(n=6)
+    move, probs, visits, priors = az.get_move(b, temp=0)
+    assert probs == {move: 1} and sum(visits.values()) >= 20 and abs(sum(priors.values()) - 1) < 1e-6
+    assert az.get_stats_after_move()["n_rollouts"] == 20
+    clone = az.clone()
+    assert clone.n_sim == 20 and clone.mct.nn is not az.mct.nn
+
+
+def test_trainer_self_play_equals_oracle_and_trains(tmp_path):
+    base.DEFAULT_MODELS_PATH = str(tmp_path) + "/"
+    tr = AlphaZeroTrainer(verbose=False, engine_slots=16, seed=4)
+    tr.game = "othello"
+    tr.config = OthelloConfig(board_size=6, simulations=12, episodes=24, epochs=1, batch_size=32, iterations=1,
+                              do_eval=False, data_augmentation=True)
+    torch.manual_seed(1)
+    tr.setup()
+    tr.self_play(0)
+    ref = O.selfplay(O.OTHELLO, 6, 6, 24, 12, ("conv", oracle_net(tr.nn, 6)), seed=4)
+    S = len(ref["z"])
+    orig = [s for s in tr.memory if s.transformation is None]
+    assert len(orig) == S and len(tr.memory) > 4 * S
+    assert np.array_equal(np.array([s.state for s in orig]).astype(np.int8), ref["state"])
+    assert np.array_equal(np.array([s.pi for s in orig]).astype(np.float32), ref["pi"])
+    assert np.array_equal(np.array([s.outcome for s in orig]), ref["z"])
+    assert [s.episode_idx for s in orig] == list(ref["meta"][:, 0]) and [s.move_idx for s in orig] == list(ref["meta"][:, 1])
+    w0 = tr.nn.fc1.weight.detach().clone()
+    tr.optimize_network(0)
+    tr.update_network(0)
+    assert not torch.equal(w0, tr.nn.fc1.weight) and tr.az_player.mct.nn is tr.nn
+    assert len(tr.loss_values[0][0]["pi"]) == len(tr.memory) // 32
+    tr.self_play(1)  # second iteration: re-uploaded weights, new game ids
+    assert tr.device_samples["meta"][:, 0].min().item() >= 24
+
+
+def test_trainer_full_loop_tictactoe(tmp_path):
+    base.DEFAULT_MODELS_PATH = str(tmp_path) + "/"
+    cfg = TicTacToeConfig(simulations=8, episodes=32, epochs=1, batch_size=16, iterations=2, eval_opponent="random",
+                          eval_episodes=4, do_eval=True)
+    path = os.path.join(tmp_path, "cfg.json")
+    json.dump(cfg.to_dict(), open(path, "w"))
+    tr = AlphaZeroTrainer(verbose=False, engine_slots=32)
+    tr.train(game="tictactoe", experiment_name="ttt-test", json_config_file=path)
+    d = os.path.join(tmp_path, "ttt-test")
+    for f in ("config.json", "loss.json", "eval.json", "ttt-test.pt", "checkpoints/ttt-test-chkpt-2.pt"):
+        assert os.path.exists(os.path.join(d, f)), f
+    ev = json.load(open(os.path.join(d, "eval.json")))
+    assert ev["eval_opponent"] == "random" and set(ev["results"]) == {"0", "1"}
+    from alphazero_amd.games.tictactoe import TicTacToeNet
+    net = TicTacToeNet.from_pretrained("ttt-test", models_path=str(tmp_path))
+    assert net.get_parameters_count() == 316
