@@ -73,6 +73,7 @@ struct EngDev {
     uint8_t *pool_sel;  // which of the slot's two pools holds the live tree
     float *nn_in, *probs, *value;
     int *row_of_slot;  // network batch row holding the slot's pending leaf (leaves are compacted)
+    int *evals;        // per-slot network evaluations since the last move (folded into ctr[] once per ply)
     int *batch_cnt;    // [3] rows filled: two alternating lock-step counters + the root-prior pass
     int *samp_idx;
     int8_t *o_state; float *o_pi; int8_t *o_z; int *o_meta, *o_visits;
@@ -152,21 +153,35 @@ AZ_D void write_nn_input_grp(const EngDev &E, int row, const BB &b, int sub) {
 }
 
 // get_normalized_probs (othello.py:384-402, connect4.py:414-428, tictactoe.py:318-334) + add_child,
-// one lane per legal action bit; returns false on pool exhaustion
-AZ_D bool create_children_grp(const EngDev &E, int g, int node, const BB &bb, const float *pr, int sub) {
+// one lane per legal action bit.  `fc` = the slot's bump pointer (first free node); returns the number of
+// children created, or -1 on pool exhaustion.
+AZ_D int create_children_grp(const EngDev &E, int g, Node *pool, int fc, int node, const BB &bb, const float *pr, int sub) {
     const GameDesc &gd = E.gd;
-    Node *pool = pool_of(E, g);
     u64 bits = az_legal_bits_grp(gd, bb, bb.player, sub);
     bool pass = (gd.game == AZ_OTHELLO && bits == 0);
     int k = pass ? 1 : __popcll(bits);
-    int fc = E.n_nodes[g];
-    if (k <= 0 || fc + k > E.C) { if (sub == 0) atomicOr(E.err, k <= 0 ? ERR_INTERNAL : ERR_NODE_POOL); return false; }
-    float s = 0.0f;  // float32 running sum in ascending action order (every lane, same result)
-    if (pass) s += pr[gd.A - 1];
-    else for (u64 m = bits; m; m &= m - 1) s += pr[az_bit_to_action(gd, __ffsll((long long)m) - 1)];
+    if (k <= 0 || fc + k > E.C) { if (sub == 0) atomicOr(E.err, k <= 0 ? ERR_INTERNAL : ERR_NODE_POOL); return -1; }
+    // priors of this lane's (up to 4) legal actions: independent loads, one round trip for the whole row
+    float myp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int bit = r * LPG + sub;
+        myp[r] = (!pass && ((bits >> bit) & 1ULL)) ? pr[az_bit_to_action(gd, bit)] : 0.0f;
+    }
+    const float ppass = pass ? pr[gd.A - 1] : 0.0f;
+    // float32 running sum in ASCENDING action order, as the reference accumulates it: the operands come from
+    // their lanes by shuffle, so the order is kept without a dependent global load per action
+    float s = 0.0f;
+    if (pass) s += ppass;
+    else
+        for (u64 m = bits; m; m &= m - 1) {
+            const int bit = __ffsll((long long)m) - 1, r = bit >> 4;
+            const float mine = r == 0 ? myp[0] : (r == 1 ? myp[1] : (r == 2 ? myp[2] : myp[3]));
+            s += __shfl(mine, bit & 15, LPG);
+        }
     bool uniform = s < 1e-6f;
     if (pass) {
-        if (sub == 0) store_node(pool + fc, fresh_node(gd.A - 1, node, uniform ? 1.0 : (double)(pr[gd.A - 1] / s), uniform ? 0 : F_PF32));
+        if (sub == 0) store_node(pool + fc, fresh_node(gd.A - 1, node, uniform ? 1.0 : (double)(ppass / s), uniform ? 0 : F_PF32));
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -174,18 +189,17 @@ AZ_D bool create_children_grp(const EngDev &E, int g, int node, const BB &bb, co
             if ((bits >> bit) & 1ULL) {
                 int idx = __popcll(bits & ((1ULL << bit) - 1ULL));
                 int a = az_bit_to_action(gd, bit);
-                store_node(pool + fc + idx, fresh_node(a, node, uniform ? 1.0 / (double)k : (double)(pr[a] / s), uniform ? 0 : F_PF32));
+                store_node(pool + fc + idx, fresh_node(a, node, uniform ? 1.0 / (double)k : (double)(myp[r] / s), uniform ? 0 : F_PF32));
             }
         }
     }
     if (sub == 0) {
         E.n_nodes[g] = fc + k;
-        atomicMax(E.max_nodes, fc + k);
         pool[node].first = fc;
         pool[node].nch = (uint8_t)k;
         pool[node].flags |= F_EVALUATED;
     }
-    return true;
+    return k;
 }
 
 // fair_max over PUCT (mcts.py:44-46, 137; utils.py:28-34): one lane per child, 16 children per round.
@@ -313,22 +327,21 @@ AZ_D void apply_root_noise_grp(const EngDev &E, int g, Node *pool, int root, con
 
 // back_propagate (mcts.py:197-223).  The select step recorded the root..leaf path, so every node on it
 // is updated by its own lane in one memory round trip (reward sign alternates from the leaf up);
-// paths longer than 16 nodes fall back to chasing parent pointers.
-AZ_D void back_propagate_grp(const EngDev &E, int g, Node *pool, int leaf, int player_to_play, double outcome, int sub) {
+// paths longer than 16 nodes fall back to chasing parent pointers.  `mine` = this lane's path node (already
+// loaded), returns true when the fast path ran (lane 0 then holds the root with its N already incremented).
+AZ_D bool back_propagate_grp(Node *pool, int len, int my_node, Node &mine, int leaf, int player_to_play, double outcome, int sub) {
     double reward;
     if (fabs(outcome) < 1e-4) reward = 0.0;
     else reward = ((double)player_to_play * outcome > 0.0) ? -fabs(outcome) : fabs(outcome);
-    const int len = E.path_len[g];
     if (len <= LPG) {
         if (sub < len) {
-            const int node = E.path[(size_t)g * LPG + sub];
             const int up = len - 1 - sub;  // edges above the leaf
-            Node n = load_node(pool + node);
             const double r = (reward == 0.0) ? 0.0 : ((up & 1) ? -reward : reward);
-            pool[node].Q = ((double)n.N * n.Q + r) / (double)(n.N + 1);
-            pool[node].N = n.N + 1;
+            pool[my_node].Q = ((double)mine.N * mine.Q + r) / (double)(mine.N + 1);
+            pool[my_node].N = mine.N + 1;
+            mine.N += 1;
         }
-        return;
+        return true;
     }
     int node = leaf;
     while (node >= 0) {
@@ -340,6 +353,7 @@ AZ_D void back_propagate_grp(const EngDev &E, int g, Node *pool, int leaf, int p
         node = n.parent;
         reward = (reward == 0.0) ? 0.0 : -reward;
     }
+    return false;
 }
 
 AZ_D void reset_slot(const EngDev &E, int g, u32 game_id) {
@@ -347,7 +361,7 @@ AZ_D void reset_slot(const EngDev &E, int g, u32 game_id) {
     start_position(E.gd, b);
     E.root_p1[g] = b.p1; E.root_m1[g] = b.m1; E.root_player[g] = (int8_t)b.player;
     E.root[g] = 0; E.n_nodes[g] = 1; E.ply[g] = 0; E.game_id[g] = game_id; E.active[g] = 1;
-    E.leaf_status[g] = LS_NONE;
+    E.leaf_status[g] = LS_NONE; E.evals[g] = 0;
     store_node(pool_of(E, g), fresh_node(0, -1, 0.0, 0));
 }
 
@@ -394,9 +408,16 @@ __global__ __launch_bounds__(256) void k_root_init(EngDev E, int g0, int g1) {
     const int g = g0 + blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
     if (g >= g1 || !E.root_fresh[g]) return;
     BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
-    create_children_grp(E, g, E.root[g], b, E.probs + (size_t)E.row_of_slot[g] * E.A, sub);
-    if (sub == 0) atomicAdd(&E.ctr[CTR_NET_EVALS], 1ULL);
+    create_children_grp(E, g, pool_of(E, g), E.n_nodes[g], E.root[g], b, E.probs + (size_t)E.row_of_slot[g] * E.A, sub);
+    if (sub == 0) E.evals[g] += 1;
 }
+
+#ifdef AZ_PROBE  // diagnostic build only (make PROBE=1)
+__device__ unsigned long long az_step_probe[4096 * 8];
+#define PSTAMP(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); pt[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PSTAMP(i)
+#endif
 
 // One lock-step of the search for every slot:
 //   BACKUP : nn_evaluation bookkeeping (mcts.py:188-191) + back_propagate (mcts.py:197-223) of the
@@ -409,84 +430,147 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
     // this step's leaves are compacted into rows [0, batch_cnt[sim & 1]); the other counter (read by the
     // previous step's network kernels, which have completed) is cleared for the next step
     if (blockIdx.x == 0 && threadIdx.x == 0 && g0 == 0) { E.batch_cnt[(sim + 1) & 1] = 0; if (!SELECT) E.batch_cnt[2] = 0; }
-    if (g >= g1) return;
-    Node *pool = pool_of(E, g);
-    if (BACKUP) {
-        int st = E.leaf_status[g];
-        if (st != LS_NONE) {
-            int node = E.leaf[g];
-            BB b = {E.leaf_p1[g], E.leaf_m1[g], E.leaf_player[g]};
-            double outcome;
-            bool ok = true;
-            if (st == LS_EVAL) {
-                const int row = E.row_of_slot[g];
-                ok = create_children_grp(E, g, node, b, E.probs + (size_t)row * E.A, sub);
-                outcome = (double)b.player * (double)E.value[row];  // base.py:366
-                if (sub == 0) { if (ok) atomicAdd(&E.ctr[CTR_NET_EVALS], 1ULL); else E.active[g] = 0; }
-            } else {
-                outcome = (double)E.leaf_winner[g];
-            }
-            if (ok) back_propagate_grp(E, g, pool, node, b.player, outcome, sub);
-            if (sub == 0) E.leaf_status[g] = LS_NONE;
-        }
-        // the group's own stores (other lanes) must be visible to the loads below
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#ifdef AZ_PROBE
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    PSTAMP(0)
+    if (g >= g1) {  // out-of-range group: nothing to do, but it must still meet the block's barriers below
+        if (SELECT) { __shared__ int dummy; (void)dummy; __syncthreads(); __syncthreads(); __syncthreads(); }
+        return;
     }
-    if (!SELECT) return;
-    if (!E.active[g]) { if (sub == 0) E.leaf_status[g] = LS_NONE; return; }
+    // ---- every per-slot word is fetched here, in one batch of independent loads: the kernel is bound by
+    // ---- the number of DEPENDENT memory round trips (~1 us each), not by bytes
+    Node *pool = pool_of(E, g);
+    const int st = BACKUP ? E.leaf_status[g] : LS_NONE;
+    const int leaf = BACKUP ? E.leaf[g] : 0;
+    const BB lb = {BACKUP ? E.leaf_p1[g] : 0, BACKUP ? E.leaf_m1[g] : 0, BACKUP ? E.leaf_player[g] : 1};
+    const int row_prev = BACKUP ? E.row_of_slot[g] : 0;
+    const int plen_prev = BACKUP ? E.path_len[g] : 0;
+    const int path_prev = BACKUP ? E.path[(size_t)g * LPG + sub] : 0;
+    const int lwin = BACKUP ? E.leaf_winner[g] : 0;
+    int n_nodes = E.n_nodes[g];
+    int evals = E.evals[g];
+    bool active = E.active[g] != 0;
     const int ply = E.ply[g];
     BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
     int node = E.root[g];
-    Node cur = load_node(pool + node);
-    if (E.noise_mode != AZ_NOISE_OFF && E.alpha >= 0.0 && E.eps >= 0.0 && (cur.flags & F_EXPANDED) && !(cur.flags & F_NOISED)) {
-        apply_root_noise_grp(E, g, pool, node, cur, b, ply, sim, sub);
-        cur.flags |= F_NOISED;
+    Node fwd;
+    bool have_root = false;
+    PSTAMP(1)
+    if (BACKUP && st != LS_NONE) {
+        // path nodes and the network row are fetched together (second round trip)
+        Node mine;
+        const bool on_path = plen_prev <= LPG && sub < plen_prev;
+        if (on_path) mine = load_node(pool + path_prev);
+        double outcome;
+        bool ok = true;
+        if (st == LS_EVAL) {
+            const float v = E.value[row_prev];
+            int k = create_children_grp(E, g, pool, n_nodes, leaf, lb, E.probs + (size_t)row_prev * E.A, sub);
+            ok = k > 0;
+            n_nodes += ok ? k : 0;
+            outcome = (double)lb.player * (double)v;  // base.py:366
+            if (ok) evals += 1;
+            else { active = false; if (sub == 0) E.active[g] = 0; }
+        } else {
+            outcome = (double)lwin;
+        }
+        PSTAMP(2)
+        if (ok) {
+            bool fast = back_propagate_grp(pool, plen_prev, path_prev, mine, leaf, lb.player, outcome, sub);
+            if (fast && SELECT) {  // lane 0 holds the root (path[0]) with its new visit count: forward it
+                fwd.N = __shfl(mine.N, 0, LPG);
+                fwd.first = __shfl(mine.first, 0, LPG);
+                const u32 pk = (u32)__shfl((int)((u32)mine.nch | ((u32)mine.act << 8) | ((u32)mine.flags << 16) | ((u32)(uint8_t)mine.win << 24)), 0, LPG);
+                fwd.nch = (uint8_t)(pk & 0xff); fwd.act = (uint8_t)((pk >> 8) & 0xff); fwd.flags = (uint8_t)((pk >> 16) & 0xff);
+                fwd.win = (int8_t)(pk >> 24);
+                fwd.Q = 0.0; fwd.P = 0.0; fwd.parent = -1;
+                // the root itself may be the leaf that just got its children (first visit of an unexpanded root)
+                have_root = (leaf != node) || st != LS_EVAL;
+            }
+        }
+        if (sub == 0) E.leaf_status[g] = LS_NONE;
+        // the group's own stores (other lanes) must be visible to the loads below
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
-    int depth = 0, plen = 1;
-    int my_path = sub == 0 ? node : -1;  // lane i keeps the i-th node of the root..leaf path
+    PSTAMP(3)
+    if (BACKUP && sub == 0) E.evals[g] = evals;
+    if (!SELECT) return;
+    // From here on no group may leave early: the leaf rows are handed out per BLOCK (one global atomic per
+    // 16 games instead of one per game on a single hot address) behind two workgroup barriers.
+    __shared__ int s_need, s_base;
+    if (threadIdx.x == 0) s_need = 0;
+    int status = LS_NONE, w = 0, depth = 0, plen = 1;
+    int my_path = -1;
     bool bad = false;
-    for (;;) {
-        if (cur.flags & F_EXPANDED) {
+    Node cur;
+    if (active) {
+        if (have_root) cur = fwd; else cur = load_node(pool + node);
+        if (E.noise_mode != AZ_NOISE_OFF && E.alpha >= 0.0 && E.eps >= 0.0 && (cur.flags & F_EXPANDED) && !(cur.flags & F_NOISED)) {
+            apply_root_noise_grp(E, g, pool, node, cur, b, ply, sim, sub);
+            cur.flags |= F_NOISED;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        PSTAMP(4)
+        my_path = sub == 0 ? node : -1;  // lane i keeps the i-th node of the root..leaf path
+        for (;;) {
+            if (cur.flags & F_EXPANDED) {
+                Node ch;
+                int c = pick_child_grp(E, g, pool, cur, ply, sim, depth++, sub, ch);
+                node = c; cur = ch;
+                if (sub == plen) my_path = c;
+                ++plen;
+                az_play_grp(E.gd, b, cur.act, sub);
+                if (cur.N == 0) break;  // mcts.py:143-144
+                continue;
+            }
+            if (cur.flags & F_TERMINAL) break;  // mcts.py:146-147
+            if (!(cur.flags & F_EVALUATED)) { bad = true; break; }
+            cur.flags |= F_EXPANDED;  // mcts.py:151-160 : children become visible now
+            if (sub == 0) pool[node].flags = cur.flags;
             Node ch;
-            int c = pick_child_grp(E, g, pool, cur, ply, sim, depth++, sub, ch);
+            int c = pick_child_grp(E, g, pool, cur, ply, sim, depth, sub, ch);
             node = c; cur = ch;
             if (sub == plen) my_path = c;
             ++plen;
             az_play_grp(E.gd, b, cur.act, sub);
-            if (cur.N == 0) break;  // mcts.py:143-144
-            continue;
+            break;
         }
-        if (cur.flags & F_TERMINAL) break;  // mcts.py:146-147
-        if (!(cur.flags & F_EVALUATED)) { bad = true; break; }
-        cur.flags |= F_EXPANDED;  // mcts.py:151-160 : children become visible now
-        if (sub == 0) pool[node].flags = cur.flags;
-        Node ch;
-        int c = pick_child_grp(E, g, pool, cur, ply, sim, depth, sub, ch);
-        node = c; cur = ch;
-        if (sub == plen) my_path = c;
-        ++plen;
-        az_play_grp(E.gd, b, cur.act, sub);
-        break;
+        PSTAMP(5)
+        E.path[(size_t)g * LPG + sub] = my_path;
+        if (sub == 0) E.path_len[g] = plen;
+        if (bad) { if (sub == 0) atomicOr(E.err, ERR_INTERNAL); }
+        else if (cur.flags & F_TERMINAL) { status = LS_TERM; w = cur.win; }
+        else if (az_status_grp(E.gd, b, &w, sub)) {  // mcts.py:185-186
+            status = LS_TERM;
+            if (sub == 0) { pool[node].flags = cur.flags | F_TERMINAL; pool[node].win = (int8_t)w; }
+        } else {
+            status = LS_EVAL;
+        }
     }
-    E.path[(size_t)g * LPG + sub] = my_path;
-    if (sub == 0) E.path_len[g] = plen;
-    if (bad) { if (sub == 0) { atomicOr(E.err, ERR_INTERNAL); E.leaf_status[g] = LS_NONE; } return; }
-    int status, w = 0;
-    if (cur.flags & F_TERMINAL) { status = LS_TERM; w = cur.win; }
-    else if (az_status_grp(E.gd, b, &w, sub)) {  // mcts.py:185-186
-        status = LS_TERM;
-        if (sub == 0) { pool[node].flags = cur.flags | F_TERMINAL; pool[node].win = (int8_t)w; }
-    } else {
-        status = LS_EVAL;
-        const int row = alloc_row_grp(E.batch_cnt + (sim & 1), sub);
+    __syncthreads();
+    int rank = 0;
+    if (status == LS_EVAL && sub == 0) rank = atomicAdd(&s_need, 1);  // LDS atomic
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_need > 0 ? atomicAdd(E.batch_cnt + (sim & 1), s_need) : 0;
+    __syncthreads();
+    if (status == LS_EVAL) {
+        const int row = s_base + __shfl(rank, 0, LPG);
         write_nn_input_grp(E, row, b, sub);
         if (sub == 0) E.row_of_slot[g] = row;
     }
     if (sub == 0) {
-        E.leaf[g] = node; E.leaf_p1[g] = b.p1; E.leaf_m1[g] = b.m1; E.leaf_player[g] = (int8_t)b.player;
-        E.leaf_status[g] = (int8_t)status; E.leaf_winner[g] = (int8_t)w;
+        if (active) { E.leaf[g] = node; E.leaf_p1[g] = b.p1; E.leaf_m1[g] = b.m1; E.leaf_player[g] = (int8_t)b.player; E.leaf_winner[g] = (int8_t)w; }
+        E.leaf_status[g] = (int8_t)status;
     }
+    PSTAMP(6)
+#ifdef AZ_PROBE
+    if (BACKUP && SELECT && sim == 50 && (threadIdx.x & 63) == 0) {
+        unsigned long long *o = az_step_probe + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = pt[i];
+        o[7] = (unsigned long long)depth;
+    }
+#endif
 }
 
 AZ_D double linear_temp(int step, int tmax, int tmin) {  // schedulers.py:33-40
@@ -572,6 +656,9 @@ __global__ void k_move(EngDev E) {
     pool[chosen].parent = -1;  // mcts.py:121-123
     E.ply[g] = ply + 1;
     atomicAdd(&E.ctr[CTR_PLIES], 1ULL);
+    atomicAdd(&E.ctr[CTR_NET_EVALS], (unsigned long long)E.evals[g]);
+    E.evals[g] = 0;
+    atomicMax(E.max_nodes, E.n_nodes[g]);
     int w = 0;
     if (az_status(gd, b, &w)) {  // trainer.py:235, 262-265
         for (int p = 0; p <= ply; ++p) {
@@ -764,7 +851,7 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
     A_(active, G); A_(root_fresh, G); A_(leaf, G); A_(leaf_p1, G); A_(leaf_m1, G); A_(leaf_player, G);
     A_(leaf_status, G); A_(leaf_winner, G); A_(path, G * LPG); A_(path_len, G);
     A_(nodes, 2 * NC); A_(pool_sel, G);
-    A_(nn_in, G * gd.cells); A_(probs, G * gd.A); A_(value, G); A_(row_of_slot, G); A_(batch_cnt, 4);
+    A_(nn_in, G * gd.cells); A_(probs, G * gd.A); A_(value, G); A_(row_of_slot, G); A_(evals, G); A_(batch_cnt, 4);
     A_(samp_idx, G * (size_t)d.max_plies);
     A_(o_state, S * gd.cells); A_(o_pi, S * gd.A); A_(o_z, S); A_(o_meta, S * 4); A_(o_visits, S * gd.A);
     A_(ctr, CTR_COUNT); A_(err, 1); A_(max_nodes, 1);
@@ -972,3 +1059,10 @@ extern "C" int az_engine_play(az_engine *e, const int32_t *h_actions, int32_t n,
     AZ_TRY(fetch_counters(e));
     return check_err(e);
 }
+
+#ifdef AZ_PROBE
+extern "C" int az_debug_read_step_probe(unsigned long long *h_out, int n_words) {
+    AZ_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(az_step_probe), sizeof(unsigned long long) * (size_t)n_words));
+    return AZ_OK;
+}
+#endif
