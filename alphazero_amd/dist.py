@@ -21,6 +21,8 @@ def all_gather_samples(samples, group=None):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return samples
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":  # CPU rehearsal of the N > 1 path: gloo gathers host copies
+        samples = {k: v.cpu() for k, v in samples.items()}
     any_t = next(iter(samples.values()))
     n_local = torch.tensor([any_t.shape[0]], dtype=torch.int64, device=any_t.device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]

@@ -4,8 +4,9 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one self-play wave: every rank plays `--games` (default 4096) concurrent Othello 8x8
-games from the start position to the end at 100 MCTS simulations per move through the HIP engine
+A "step" is `--waves` (1) self-play wave(s): every rank keeps `--games` (4096) Othello 8x8 games resident and
+plays waves x games of them from the start position to the end at 100 MCTS simulations per move through the
+HIP engine (finished slots are refilled at once)
 (random-init OthelloNet(n=8) under torch.manual_seed(0), Dirichlet noise 0.03/0.25, tau linear(4,4),
 tree reuse) and, for N > 1, all-gathers the samples over RCCL.  value = games of all ranks / time.
 """
@@ -50,7 +51,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU (= games per step per GPU)")
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games (engine slots) per GPU")
+    ap.add_argument("--waves", type=int, default=1, help="games per step per GPU = waves x games; finished slots are refilled, "
+                                                           "so the ragged end of a wave (games last 60-65 plies) overlaps the next")
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -60,9 +63,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # AZ_BENCH_BACKEND=gloo + AZ_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 control flow on a one-GPU box
+    backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
+    if os.environ.get("AZ_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from alphazero_amd import engine as E
     from alphazero_amd.dist import all_gather_samples, rank_game_range
@@ -74,7 +84,7 @@ def main():
     hnet = model.to_hip(max_batch=G)
     eng = E.SelfPlayEngine(0, n, n, n_slots=G, n_sim=args.sims, net=hnet, dirichlet_alpha=0.03, dirichlet_epsilon=0.25,
                            temp_max_step=4, temp_min_step=4, tie_mode=E.TIE_RANDOM, noise_mode=E.NOISE_PHILOX,
-                           seed=0, max_plies=128, sample_capacity=G * 72)
+                           seed=0, max_plies=128, sample_capacity=args.waves * G * 72)
 
     def sync():
         torch.cuda.synchronize()
@@ -83,7 +93,7 @@ def main():
             torch.cuda.synchronize()
 
     def step(wave):
-        first, cnt = rank_game_range(rank, world, G, wave)
+        first, cnt = rank_game_range(rank, world, args.waves * G, wave)
         eng.run(cnt, first_game_id=first)
         smp = eng.samples(copy=False)
         if world > 1:
@@ -99,14 +109,14 @@ def main():
         n_samples_total += step(args.warmup + k)
     sync()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     st = eng.stats()
 
     if rank == 0:
-        games = args.steps * G * world
+        games = args.steps * args.waves * G * world
         samples = n_samples_total  # after the all-gather every rank holds all ranks' samples
         out = {
             "metric": "self-play games/sec (whole node), Othello 8x8 @100 sims/move", "value": games / dt, "unit": "games/s",
@@ -114,7 +124,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Othello 8x8, {G} concurrent self-play games per GPU, {args.sims} sims/move, "
                                    f"random-init OthelloNet(n=8) seed 0, Dirichlet 0.03/0.25, tau linear(4,4), tree reuse",
-                       "games_per_gpu_per_step": G, "sims_per_move": args.sims, "parallelism": f"game-sharded x{world}"},
+                       "games_per_gpu_per_step": args.waves * G, "concurrent_games_per_gpu": G, "sims_per_move": args.sims,
+                       "parallelism": f"game-sharded x{world}"},
             "examples_per_sec": samples / dt, "sims_per_sec": samples * args.sims / dt,
             "plies_per_game": samples / games, "net_evals_last_step": st["net_evals"], "lockstep_iters_last_step": st["lockstep_iters"],
             "max_tree_nodes_per_game": st["max_nodes_used"],
