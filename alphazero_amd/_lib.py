@@ -38,7 +38,7 @@ SYMBOLS = [
     "az_net_action_size",
     "az_net_flops_per_board", "az_net_time_stage", "az_engine_create", "az_engine_destroy", "az_engine_run",
     "az_engine_get_stats", "az_engine_samples", "az_engine_set_roots", "az_engine_search", "az_engine_advance",
-    "az_engine_root_children", "az_engine_play",
+    "az_engine_root_children", "az_engine_play", "az_augment_count", "az_augment",
 ]
 
 
@@ -77,6 +77,8 @@ def lib():
     L.az_engine_search.argtypes = [vp, i32]
     L.az_engine_advance.argtypes = [vp]
     L.az_engine_play.argtypes = [vp, vp, i32, vp]
+    L.az_augment_count.argtypes = [C.c_int, vp, i64, C.POINTER(i64), vp]
+    L.az_augment.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.az_engine_root_children.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     _LIB = L
     return L

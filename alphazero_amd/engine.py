@@ -78,6 +78,27 @@ def status_batch(game_id, H, W, grids, players):
     return over, win, score
 
 
+def augment_samples(game_id, H, W, samples):
+    """symmetry twins of the samples with move_idx >= 2, in the reference's order (trainer.py:275-284).
+    samples: dict of CUDA tensors (state int8 [S,H,W], pi float32 [S,A], z int8 [S], meta int32 [S,4]).
+    Returns the twins as a dict of the same form; meta[:, 3] is the transformation code 1..7."""
+    st, pi, z, meta = (samples[k].contiguous() for k in ("state", "pi", "z", "meta"))
+    S, A = z.shape[0], pi.shape[1]
+    n = C.c_int64()
+    check(lib().az_augment_count(game_id, meta.data_ptr() if S else None, S, C.byref(n), _stream_ptr()))
+    N = n.value
+    out = {"state": torch.empty((N, H, W), dtype=torch.int8, device=st.device), "pi": torch.empty((N, A), dtype=torch.float32, device=st.device),
+           "z": torch.empty(N, dtype=torch.int8, device=st.device), "meta": torch.empty((N, 4), dtype=torch.int32, device=st.device)}
+    if N:
+        check(lib().az_augment(game_id, H, W, st.data_ptr(), pi.data_ptr(), z.data_ptr(), meta.data_ptr(), S, out["state"].data_ptr(),
+                               out["pi"].data_ptr(), out["z"].data_ptr(), out["meta"].data_ptr(), N, _stream_ptr()))
+    return out
+
+
+TRANSFORM_NAMES = [None, "reflection_horizontal", "rotation_90", "reflection_horizontal+rotation_90", "rotation_180",
+                   "reflection_horizontal+rotation_180", "rotation_270", "reflection_horizontal+rotation_270"]
+
+
 # ---------------------------------------------------------------------------------------------- network
 class HipNet:
     """Device policy-value network built from a reference state_dict (eval-mode BN folded at upload)."""

@@ -61,7 +61,7 @@ def augment(memory, nn, strategy):
 class AlphaZeroTrainer:
     DEFAULT_EXP_NAME = "alphazero-undefined"
 
-    def __init__(self, verbose=False, engine_slots=4096, seed=0):
+    def __init__(self, verbose=False, engine_slots=4096, seed=0, materialize_memory=True):
         self.game = self.config = self.board = self.nn = self.nn_twin = None
         self.az_player = self.temp_scheduler = self.data_augment_strategy = None
         self.memory = self.loss_values = self.eval_results = None
@@ -69,6 +69,9 @@ class AlphaZeroTrainer:
         self.engine_slots, self.seed = engine_slots, seed
         self._engine = self._hipnet = None
         self.device_samples = None  # the last self-play wave as CUDA tensors (state, pi, z, meta, visits)
+        self.device_memory = None   # originals + symmetry twins as CUDA tensors: what optimize_network trains on
+        # list[Sample] like the reference's trainer.memory; switch off for large runs (millions of Python objects)
+        self.materialize_memory = materialize_memory
 
     def __str__(self):
         return f"{type(self).__name__}{self.game.capitalize()}" if self.game is not None else type(self).__name__
@@ -115,35 +118,53 @@ class AlphaZeroTrainer:
         return self._engine
 
     def self_play(self, iter_idx):
-        """trainer.py:215-286: fills self.memory with normalised samples (+ symmetry twins)"""
+        """trainer.py:215-286: all episodes are played concurrently on the engine; samples (normalised) and their
+        symmetry twins stay on the device in self.device_memory; self.memory mirrors them as Sample objects"""
+        from .engine import TRANSFORM_NAMES, augment_samples
         eng = self._ensure_engine()
+        gid, H, W, A = self._shape()
         n = self.config.episodes
         smp = eng.run(n, first_game_id=iter_idx * n)
+        meta = smp["meta"]
+        order = torch.argsort(meta[:, 0].long() * 4096 + meta[:, 1].long())  # (episode, move) order of the reference's loop
+        smp = {k: v[order].contiguous() for k, v in smp.items()}
+        smp["meta"][:, 0] -= iter_idx * n  # episode_idx counts from 0 in every iteration
         self.device_samples = smp
-        meta = smp["meta"].cpu().numpy()
-        order = np.lexsort((meta[:, 1], meta[:, 0]))
-        state = smp["state"].cpu().numpy()[order].astype(np.float64)
-        pi = smp["pi"].cpu().numpy()[order].astype(np.float64)
-        z = smp["z"].cpu().numpy()[order]
-        meta = meta[order]
-        first = iter_idx * n
-        self.memory = [Sample(state=state[i], pi=pi[i], player=1, outcome=int(z[i]), episode_idx=int(meta[i, 0]) - first,
-                              move_idx=int(meta[i, 1])) for i in range(len(z))]
+        parts = [smp]
         if self.config.data_augmentation:
-            self.memory += augment(self.memory, self.nn, self.data_augment_strategy)
-        self.print(f"Total number of samples: {len(self.memory)}")
+            parts.append(augment_samples(gid, H, W, smp))
+        self.device_memory = {k: torch.cat([p[k] for p in parts]) for k in ("state", "pi", "z", "meta")}
+        self.memory = None
+        if self.materialize_memory:
+            st = self.device_memory["state"].cpu().numpy().astype(np.float64)
+            pi = self.device_memory["pi"].cpu().numpy().astype(np.float64)
+            z = self.device_memory["z"].cpu().numpy()
+            mt = self.device_memory["meta"].cpu().numpy()
+            S = smp["z"].shape[0]
+            self.memory = [Sample(state=st[i], pi=pi[i], player=1, outcome=int(z[i]), episode_idx=int(mt[i, 0]), move_idx=int(mt[i, 1]),
+                                  transformation=None if i < S else TRANSFORM_NAMES[mt[i, 3]]) for i in range(len(z))]
+        self.print(f"Total number of samples: {self.device_memory['z'].shape[0]}")
 
     # ------------------------------------------------------------------ optimisation (trainer.py:288-387)
+    def _n_samples(self):
+        return self.device_memory["z"].shape[0] if self.device_memory is not None else len(self.memory)
+
     def _batch_generator(self, n_batches):
+        """random batches without replacement (trainer.py:288-318); device-resident when self_play ran on the engine"""
+        bs, dev = self.config.batch_size, self.config.device
+        if self.device_memory is not None:
+            m = self.device_memory
+            idx = torch.randperm(m["z"].shape[0], device=m["z"].device)[: n_batches * bs].view(n_batches, bs)
+            for rows in idx:
+                yield (m["state"][rows].to(dev, torch.float32), m["pi"][rows].to(dev, torch.float32),
+                       m["z"][rows].to(dev, torch.float32).unsqueeze(1))
+            return
         idx = np.arange(len(self.memory))
         np.random.shuffle(idx)
-        bs = self.config.batch_size
-        shape = self.memory[0].state.shape
         for rows in idx[: n_batches * bs].reshape(n_batches, bs):
-            x = np.stack([self.memory[i].state for i in rows]).reshape((bs,) + shape)
+            x = np.stack([self.memory[i].state for i in rows])
             pi = np.stack([self.memory[i].pi for i in rows])
             z = np.array([[self.memory[i].outcome] for i in rows], dtype=np.float64)
-            dev = self.config.device
             yield (torch.tensor(x, dtype=torch.float32, device=dev), torch.tensor(pi, dtype=torch.float32, device=dev),
                    torch.tensor(z, dtype=torch.float32, device=dev))
 
@@ -155,9 +176,9 @@ class AlphaZeroTrainer:
         self.loss_values[iter_idx] = {}
         bs = self.config.batch_size
         for epoch in range(self.config.epochs):
-            n_batches = len(self.memory) // bs
+            n_batches = self._n_samples() // bs
             if n_batches == 0:
-                raise ValueError(f"Too few samples in the memory ({len(self.memory)}) to create a batch with batch_size = {bs}")
+                raise ValueError(f"Too few samples in the memory ({self._n_samples()}) to create a batch with batch_size = {bs}")
             pi_losses, v_losses = [], []
             for x, pi, z in self._batch_generator(n_batches):
                 opt.zero_grad()

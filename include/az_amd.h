@@ -142,6 +142,16 @@ int az_engine_play(az_engine *e, const int32_t *h_actions, int32_t n, int32_t *h
 int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_actions, int32_t *h_N, double *h_Q,
                             double *h_P, int32_t *count, int32_t *root_N);
 
+/* ---- symmetry augmentation on the device ------------------------------------
+ * replaces the loop of AlphaZeroTrainer.self_play (trainer.py:275-284) over Sample.create_reflection_twin /
+ * create_rotation_twin: every sample with move_idx >= 2 gets its 7 twins (Connect4: 1) in the reference's
+ * order; out meta[.][3] holds the transformation code 1..7 (1 reflection_horizontal, 2 rotation_90,
+ * 3 reflection_horizontal+rotation_90, 4 rotation_180, ...).  az_augment_count returns the number of twins. */
+int az_augment_count(int game, const int32_t *d_meta, int64_t S, int64_t *n_out, void *stream);
+int az_augment(int game, int H, int W, const int8_t *d_state, const float *d_pi, const int8_t *d_z, const int32_t *d_meta,
+               int64_t S, int8_t *d_out_state, float *d_out_pi, int8_t *d_out_z, int32_t *d_out_meta, int64_t out_capacity,
+               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,9 +93,18 @@ def test_trainer_self_play_equals_oracle_and_trains(tmp_path):
     tr.optimize_network(0)
     tr.update_network(0)
     assert not torch.equal(w0, tr.nn.fc1.weight) and tr.az_player.mct.nn is tr.nn
-    assert len(tr.loss_values[0][0]["pi"]) == len(tr.memory) // 32
-    tr.self_play(1)  # second iteration: re-uploaded weights, new game ids
-    assert tr.device_samples["meta"][:, 0].min().item() >= 24
+    assert len(tr.loss_values[0][0]["pi"]) == len(tr.memory) // 32 == tr.device_memory["z"].shape[0] // 32
+    from alphazero_amd.trainer import augment
+    host_twins = augment(orig, tr.nn, tr.data_augment_strategy)
+    dev_twins = [s for s in tr.memory if s.transformation is not None]
+    assert len(host_twins) == len(dev_twins)
+    assert all(np.array_equal(a.state, b.state) and np.array_equal(a.pi.astype(np.float32), b.pi.astype(np.float32))
+               and a.transformation == b.transformation for a, b in zip(host_twins, dev_twins))
+    first_actions = ref["meta"][:, 3].copy()
+    tr.self_play(1)  # second iteration: re-uploaded (trained) weights, fresh game ids -> different games
+    m = tr.device_samples["meta"].cpu().numpy()
+    assert m[:, 0].min() == 0 and m[:, 0].max() == 23  # episode_idx restarts at 0 (trainer.py:226)
+    assert len(m) != len(first_actions) or not np.array_equal(m[:, 3], first_actions)
 
 
 def test_trainer_full_loop_tictactoe(tmp_path):
@@ -114,3 +123,29 @@ def test_trainer_full_loop_tictactoe(tmp_path):
     from alphazero_amd.games.tictactoe import TicTacToeNet
     net = TicTacToeNet.from_pretrained("ttt-test", models_path=str(tmp_path))
     assert net.get_parameters_count() == 316
+
+
+@pytest.mark.parametrize("tag", ["othello8", "othello6", "connect4", "tictactoe"])
+def test_device_augmentation_matches_reference_memory(tag):
+    """the HIP permutation kernel against the reference's augmented memory (G4), bit-exact, same order"""
+    from conftest import TAGS, golden
+    from alphazero_amd import engine as E
+    game, gid, H, W, A, n = TAGS[tag]
+    fx = golden(f"selfplay_{tag}.npz")
+    names = [str(x) for x in fx["transf_names"]]
+    orig = fx["transformation"] == names.index("None")
+    dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+    meta = np.stack([fx["episode_idx"][orig], fx["move_idx"][orig], np.ones(orig.sum(), np.int32), np.zeros(orig.sum(), np.int32)], 1)
+    smp = {"state": dev(fx["state"][orig], torch.int8), "pi": dev(fx["pi"][orig].astype(np.float32), torch.float32),
+           "z": dev(fx["outcome"][orig], torch.int8), "meta": dev(meta, torch.int32)}
+    tw = E.augment_samples(gid, H, W, smp)
+    ref = np.flatnonzero(~orig)
+    assert tw["z"].shape[0] == len(ref)
+    assert np.array_equal(tw["state"].cpu().numpy(), fx["state"][ref])
+    assert np.array_equal(tw["pi"].cpu().numpy(), fx["pi"][ref].astype(np.float32))
+    assert np.array_equal(tw["z"].cpu().numpy(), fx["outcome"][ref])
+    m = tw["meta"].cpu().numpy()
+    assert np.array_equal(m[:, 0], fx["episode_idx"][ref]) and np.array_equal(m[:, 1], fx["move_idx"][ref])
+    assert [E.TRANSFORM_NAMES[c] for c in m[:, 3]] == [names[c] for c in fx["transformation"][ref]]
+    empty = {k: v[:0] for k, v in smp.items()}
+    assert E.augment_samples(gid, H, W, empty)["z"].shape[0] == 0
