@@ -39,6 +39,7 @@ SYMBOLS = [
     "az_net_flops_per_board", "az_net_time_stage", "az_engine_create", "az_engine_destroy", "az_engine_run",
     "az_engine_get_stats", "az_engine_samples", "az_engine_set_roots", "az_engine_search", "az_engine_advance",
     "az_engine_root_children", "az_engine_play", "az_augment_count", "az_augment",
+    "az_engine_set_sides", "az_engine_best_moves", "az_engine_baseline_moves", "az_engine_root_status",
 ]
 
 
@@ -77,6 +78,10 @@ def lib():
     L.az_engine_search.argtypes = [vp, i32]
     L.az_engine_advance.argtypes = [vp]
     L.az_engine_play.argtypes = [vp, vp, i32, vp]
+    L.az_engine_set_sides.argtypes = [vp, vp, i32]
+    L.az_engine_best_moves.argtypes = [vp, vp]
+    L.az_engine_baseline_moves.argtypes = [vp, i32, C.c_uint32, vp]
+    L.az_engine_root_status.argtypes = [vp, vp, vp, vp, vp]
     L.az_augment_count.argtypes = [C.c_int, vp, i64, C.POINTER(i64), vp]
     L.az_augment.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.az_engine_root_children.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]

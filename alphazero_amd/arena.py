@@ -55,3 +55,80 @@ class Arena:
     def print_stats_results(player1, player2, stats):
         n1, n2, d = len(stats["player1"]), len(stats["player2"]), stats["draw"]
         print(f"{player1} wins: {n1} | {player2} wins: {n2} | draws: {d}")
+
+
+class BatchedArena:
+    """Arena.play_games (arena.py:119-185) with all rounds played at once on the GPU.
+
+    player1 is an AlphaZero player (network `nn`, `n_sim` simulations, no noise, temperature 0: what
+    AlphaZeroTrainer.evaluate builds, trainer.py:421-425); `opponent` is "random", "greedy" or another network
+    (an Arena-compatible extension: evaluation against a previous network).  Returns the reference's stats dict.
+    """
+
+    def __init__(self, game, nn, opponent="random", n_sim=100, opponent_n_sim=None, seed=0, board_size=None,
+                 board_width=7, board_height=6):
+        from .engine import game_shape
+        self.game = game
+        self.gid, self.H, self.W, self.A = game_shape(game, board_size if board_size is not None else getattr(nn, "n", None),
+                                                      board_width, board_height)
+        self.nn, self.opponent, self.n_sim, self.seed = nn, opponent, n_sim, seed
+        self.opponent_n_sim = opponent_n_sim if opponent_n_sim is not None else n_sim
+
+    def _engine(self, net, G, n_sim, seed):
+        from .engine import NOISE_OFF, TIE_RANDOM, SelfPlayEngine
+        plies = 4 * self.H * self.W + 16
+        return SelfPlayEngine(self.gid, self.H, self.W, n_slots=G, n_sim=n_sim, net=net.to_hip(max_batch=G),
+                              dirichlet_alpha=None, dirichlet_epsilon=None, temp_max_step=-1, temp_min_step=0,
+                              tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed, max_plies=plies, sample_capacity=16)
+
+    def play_games(self, n_rounds, start_player=None, return_stats=True):
+        import numpy as np
+        from collections import defaultdict
+        G = n_rounds
+        p2_starts = np.array([{1: False, 2: True}.get(start_player, bool(r % 2)) for r in range(G)])
+        side1 = np.where(p2_starts, -1, 1).astype(np.int8)  # colour +1 moves first
+        board = {0: lambda: __import__("alphazero_amd.games.othello", fromlist=["OthelloBoard"]).OthelloBoard(n=self.H),
+                 1: lambda: __import__("alphazero_amd.games.connect4", fromlist=["Connect4Board"]).Connect4Board(width=self.W, height=self.H),
+                 2: lambda: __import__("alphazero_amd.games.tictactoe", fromlist=["TicTacToeBoard"]).TicTacToeBoard()}[self.gid]()
+        grids = np.tile(board.grid.astype(np.int8)[None], (G, 1, 1))
+        ones = np.ones(G, np.int8)
+        ids = np.arange(G, dtype=np.uint32) + np.uint32(self.seed * 100003)
+        e1 = self._engine(self.nn, G, self.n_sim, self.seed)
+        e1.set_roots(grids, ones, game_ids=ids)
+        e1.set_sides(side1)
+        e2 = None
+        if not isinstance(self.opponent, str):
+            e2 = self._engine(self.opponent, G, self.opponent_n_sim, self.seed + 1)
+            e2.set_roots(grids, ones, game_ids=ids)
+            e2.set_sides(-side1)
+        for _ in range(4 * self.H * self.W + 8):
+            _, over, winner, score = e1.root_status()
+            if over.all():
+                break
+            e1.search(self.n_sim)
+            a = e1.best_moves()
+            if e2 is not None:
+                e2.search(self.opponent_n_sim)
+                b = e2.best_moves()
+            else:
+                b = e1.baseline_moves(self.opponent, seed=self.seed + 7)
+            moves = np.where(a >= 0, a, b).astype(np.int32)
+            e1.play(moves)
+            if e2 is not None:
+                e2.play(moves)
+        else:
+            raise RuntimeError("arena games did not finish")
+        stats = {"player1": [], "player2": [], "draw": 0, "player1_starts": defaultdict(int), "player2_starts": defaultdict(int)}
+        for g in range(G):
+            starter = f"player{2 if p2_starts[g] else 1}_starts"
+            if winner[g] == 0:
+                stats["draw"] += 1
+                stats[starter]["draw"] += 1
+            else:
+                who = 1 if winner[g] == side1[g] else 2
+                stats[f"player{who}"].append(int(abs(score[g])))
+                stats[starter]["win" if who == (2 if p2_starts[g] else 1) else "loss"] += 1
+        e1.close()
+        if e2 is not None:
+            e2.close()
+        return stats if return_stats else None

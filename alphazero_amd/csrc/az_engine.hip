@@ -67,6 +67,7 @@ struct EngDev {
     long long sample_cap;
     u64 *root_p1, *root_m1; int8_t *root_player;
     int *root, *n_nodes, *ply; u32 *game_id; uint8_t *active, *root_fresh;
+    int8_t *side;  // arena: the colour this engine searches for in the slot (0 = both, self-play)
     int *leaf; u64 *leaf_p1, *leaf_m1; int8_t *leaf_player, *leaf_status, *leaf_winner;
     int *path, *path_len;  // root..leaf node indices of the pending simulation ([G][LPG]; longer paths chase parents)
     Node *nodes;        // [G][2][C]
@@ -113,6 +114,9 @@ AZ_D Node fresh_node(int action, int parent, double P, int flags) {
 }
 
 AZ_D Node *pool_of(const EngDev &E, int g) { return E.nodes + ((size_t)g * 2 + E.pool_sel[g]) * E.C; }
+
+// does this engine search slot g now? (active, and in arena mode only when its colour is to move)
+AZ_D bool searches(const EngDev &E, int g) { return E.active[g] && (E.side[g] == 0 || E.side[g] == E.root_player[g]); }
 
 AZ_D u32 grp_ballot(bool p) { return (u32)(__ballot(p) >> (threadIdx.x & 48)) & 0xFFFFu; }
 AZ_D double grp_max(double v) {
@@ -361,7 +365,7 @@ AZ_D void reset_slot(const EngDev &E, int g, u32 game_id) {
     start_position(E.gd, b);
     E.root_p1[g] = b.p1; E.root_m1[g] = b.m1; E.root_player[g] = (int8_t)b.player;
     E.root[g] = 0; E.n_nodes[g] = 1; E.ply[g] = 0; E.game_id[g] = game_id; E.active[g] = 1;
-    E.leaf_status[g] = LS_NONE; E.evals[g] = 0;
+    E.leaf_status[g] = LS_NONE; E.evals[g] = 0; E.side[g] = 0;
     store_node(pool_of(E, g), fresh_node(0, -1, 0.0, 0));
 }
 
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256) void k_root_prep(EngDev E, int g0, int g1) {
     const int g = g0 + blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
     if (g >= g1) return;
     uint8_t fresh = 0;
-    if (E.active[g]) {
+    if (searches(E, g)) {
         uint8_t f = pool_of(E, g)[E.root[g]].flags;
         if (!(f & (F_EVALUATED | F_TERMINAL))) {
             fresh = 1;
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
     const int lwin = BACKUP ? E.leaf_winner[g] : 0;
     int n_nodes = E.n_nodes[g];
     int evals = E.evals[g];
-    bool active = E.active[g] != 0;
+    bool active = searches(E, g);
     const int ply = E.ply[g];
     BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
     int node = E.root[g];
@@ -726,11 +730,12 @@ __global__ __launch_bounds__(256) void k_reroot(EngDev E) {
 __global__ void k_apply_moves(EngDev E, const int *actions, int n, int *status) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n || g >= E.G) return;
+    const int a = actions[g];
+    if (a < 0) { status[g] = AZ_OK; return; }  // no move for this slot
     if (!E.active[g]) { status[g] = AZ_ESTATE; return; }
     const GameDesc &gd = E.gd;
     Node *pool = pool_of(E, g);
     BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
-    const int a = actions[g];
     u64 bits = az_legal_bits(gd, b, b.player);
     bool ok = false;
     if (a >= 0 && a < gd.A) {
@@ -750,7 +755,86 @@ __global__ void k_apply_moves(EngDev E, const int *actions, int n, int *status) 
     E.root[g] = chosen;
     E.ply[g] = E.ply[g] + 1;
     E.leaf_status[g] = LS_NONE;
+    int w = 0;
+    if (az_status(gd, b, &w)) E.active[g] = 0;  // finished: the board stays readable, the slot is no longer searched
     status[g] = AZ_OK;
+}
+
+// MCT.get_action_probs(temp=0) + fair_max (mcts.py:110-112): the most visited root child of every slot this
+// engine is to move in; -1 elsewhere.  One thread per slot.
+__global__ void k_best_moves(EngDev E, int *actions) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.G) return;
+    actions[g] = -1;
+    if (!searches(E, g)) return;
+    Node *pool = pool_of(E, g);
+    const int root = E.root[g], fc = pool[root].first, nc = pool[root].nch;
+    if (nc == 0 || !(pool[root].flags & F_EXPANDED)) return;
+    int best = -1, cnt = 0, first = 0;
+    for (int i = 0; i < nc; ++i) {
+        int n = pool[fc + i].N;
+        if (n > best) { best = n; cnt = 1; first = i; } else if (n == best) cnt++;
+    }
+    int pick = first;
+    if (E.tie_mode == AZ_TIE_RANDOM && cnt > 1) {
+        Philox4 r = az_philox(E.seed, E.game_id[g], (u32)E.ply[g], 0xFFFFu, AZ_P_TIE_MOVE, 0);
+        int k = (int)(((u64)r.x * (u64)cnt) >> 32);
+        for (int i = 0; i < nc; ++i)
+            if (pool[fc + i].N == best) { if (k == 0) { pick = i; break; } --k; }
+    }
+    actions[g] = pool[fc + pick].act;
+}
+
+// RandomPlayer / GreedyPlayer (players.py:76-123) for the slots where the OTHER colour is to move:
+// kind 0 = uniform legal move, kind 1 = best immediate -get_score() of the position after the move, ties uniform.
+__global__ void k_baseline_moves(EngDev E, int kind, u32 seed, int *actions) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.G) return;
+    actions[g] = -1;
+    if (!E.active[g] || E.side[g] == 0 || E.side[g] == E.root_player[g]) return;
+    const GameDesc &gd = E.gd;
+    BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
+    u64 bits = az_legal_bits(gd, b, b.player);
+    if (gd.game == AZ_OTHELLO && bits == 0) { actions[g] = gd.A - 1; return; }  // forced pass
+    int n = __popcll(bits);
+    if (n == 0) return;
+    u64 cand = bits;
+    if (kind == 1) {  // greedy: keep the moves with the best score
+        int best = -1000000;
+        cand = 0;
+        for (u64 m = bits; m; m &= m - 1) {
+            int bit = __ffsll((long long)m) - 1;
+            BB c = b;
+            az_play(gd, c, az_bit_to_action(gd, bit));
+            int sc;
+            if (gd.game == AZ_TICTACTOE) {  // -get_score(): -inf when the opponent can complete a line at once (tictactoe.py:119-126)
+                u64 opp = c.player > 0 ? c.p1 : c.m1, occ = c.p1 | c.m1;
+                bool threat = false;
+                const u64 L[8] = {0x7ULL, 0x7ULL << 8, 0x7ULL << 16, 0x010101ULL, 0x010101ULL << 1, 0x010101ULL << 2,
+                                  (1ULL | (1ULL << 9) | (1ULL << 18)), ((1ULL << 2) | (1ULL << 9) | (1ULL << 16))};
+                for (int l = 0; l < 8; ++l) threat |= (__popcll(opp & L[l]) == 2 && __popcll(occ & L[l]) == 2);
+                sc = threat ? -1 : 0;
+            } else {
+                sc = -(c.player * (__popcll(c.p1) - __popcll(c.m1)));  // -sum(player*grid) after the move
+            }
+            if (sc > best) { best = sc; cand = 1ULL << bit; } else if (sc == best) cand |= 1ULL << bit;
+        }
+        n = __popcll(cand);
+    }
+    Philox4 r = az_philox(seed, E.game_id[g], (u32)E.ply[g], 0xFFFEu, AZ_P_TIE_MOVE, (u32)kind);
+    int k = (int)(((u64)r.x * (u64)n) >> 32);
+    for (int i = 0; i < k; ++i) cand &= cand - 1;
+    actions[g] = az_bit_to_action(gd, __ffsll((long long)cand) - 1);
+}
+
+__global__ void k_root_status(EngDev E, int8_t *players, uint8_t *over, int8_t *winner, int *score) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.G) return;
+    BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
+    int w = 2;
+    bool o = az_status(E.gd, b, &w);
+    players[g] = (int8_t)b.player; over[g] = o ? 1 : 0; winner[g] = (int8_t)(o ? w : 2);
+    score[g] = b.player * (__popcll(b.p1) - __popcll(b.m1));
 }
 
 // closed-form fake network (tests): reads the canonical board back from nn_in
@@ -848,7 +932,7 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
     int rc = AZ_OK;
 #define A_(p, n) if (rc == AZ_OK) rc = dev_alloc(e, &d.p, (n))
     A_(root_p1, G); A_(root_m1, G); A_(root_player, G); A_(root, G); A_(n_nodes, G); A_(ply, G); A_(game_id, G);
-    A_(active, G); A_(root_fresh, G); A_(leaf, G); A_(leaf_p1, G); A_(leaf_m1, G); A_(leaf_player, G);
+    A_(active, G); A_(root_fresh, G); A_(side, G); A_(leaf, G); A_(leaf_p1, G); A_(leaf_m1, G); A_(leaf_player, G);
     A_(leaf_status, G); A_(leaf_winner, G); A_(path, G * LPG); A_(path_len, G);
     A_(nodes, 2 * NC); A_(pool_sel, G);
     A_(nn_in, G * gd.cells); A_(probs, G * gd.A); A_(value, G); A_(row_of_slot, G); A_(evals, G); A_(batch_cnt, 4);
@@ -1066,3 +1150,52 @@ extern "C" int az_debug_read_step_probe(unsigned long long *h_out, int n_words) 
     return AZ_OK;
 }
 #endif
+
+// ---- arena support ---------------------------------------------------------------
+extern "C" int az_engine_set_sides(az_engine *e, const int8_t *h_sides, int32_t n) {
+    AZ_REQUIRE(e && h_sides && n > 0 && n <= e->d.G, AZ_EINVAL, "bad arguments");
+    AZ_HIP(hipMemcpyAsync(e->d.side, h_sides, (size_t)n, hipMemcpyHostToDevice, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    return AZ_OK;
+}
+
+static int moves_out(az_engine *e, int32_t *h_actions, int which, int kind, uint32_t seed) {
+    EngDev &d = e->d;
+    int *d_act = nullptr;
+    AZ_HIP(hipMalloc((void **)&d_act, sizeof(int) * d.G));
+    if (which == 0) hipLaunchKernelGGL(k_best_moves, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, d_act);
+    else hipLaunchKernelGGL(k_baseline_moves, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, kind, (u32)seed, d_act);
+    AZ_HIP(hipMemcpyAsync(h_actions, d_act, sizeof(int) * d.G, hipMemcpyDeviceToHost, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    (void)hipFree(d_act);
+    return AZ_OK;
+}
+
+extern "C" int az_engine_best_moves(az_engine *e, int32_t *h_actions) {
+    AZ_REQUIRE(e && h_actions, AZ_EINVAL, "null argument");
+    return moves_out(e, h_actions, 0, 0, 0);
+}
+
+extern "C" int az_engine_baseline_moves(az_engine *e, int32_t kind, uint32_t seed, int32_t *h_actions) {
+    AZ_REQUIRE(e && h_actions && (kind == 0 || kind == 1), AZ_EINVAL, "bad arguments (kind: 0 random, 1 greedy)");
+    return moves_out(e, h_actions, 1, kind, seed);
+}
+
+extern "C" int az_engine_root_status(az_engine *e, int8_t *h_players, uint8_t *h_over, int8_t *h_winner, int32_t *h_score) {
+    AZ_REQUIRE(e && h_players && h_over && h_winner && h_score, AZ_EINVAL, "null argument");
+    EngDev &d = e->d;
+    char *buf = nullptr;
+    size_t G = d.G;
+    AZ_HIP(hipMalloc((void **)&buf, G * 7));
+    int8_t *pl = (int8_t *)buf; uint8_t *ov = (uint8_t *)(buf + G); int8_t *wi = (int8_t *)(buf + 2 * G);
+    int *sc = nullptr;
+    AZ_HIP(hipMalloc((void **)&sc, G * sizeof(int)));
+    hipLaunchKernelGGL(k_root_status, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, pl, ov, wi, sc);
+    AZ_HIP(hipMemcpyAsync(h_players, pl, G, hipMemcpyDeviceToHost, e->stream));
+    AZ_HIP(hipMemcpyAsync(h_over, ov, G, hipMemcpyDeviceToHost, e->stream));
+    AZ_HIP(hipMemcpyAsync(h_winner, wi, G, hipMemcpyDeviceToHost, e->stream));
+    AZ_HIP(hipMemcpyAsync(h_score, sc, G * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    (void)hipFree(buf); (void)hipFree(sc);
+    return AZ_OK;
+}

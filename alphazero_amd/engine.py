@@ -217,6 +217,27 @@ class SelfPlayEngine:
         st = np.zeros(len(a), np.int32)
         check(lib().az_engine_play(self.h, a.ctypes.data, len(a), st.ctypes.data))
 
+    # arena support -------------------------------------------------------------------------------
+    def set_sides(self, sides):
+        s = np.ascontiguousarray(sides, np.int8)
+        check(lib().az_engine_set_sides(self.h, s.ctypes.data, len(s)))
+
+    def best_moves(self):
+        a = np.zeros(self.cfg.n_slots, np.int32)
+        check(lib().az_engine_best_moves(self.h, a.ctypes.data))
+        return a
+
+    def baseline_moves(self, kind, seed=0):
+        a = np.zeros(self.cfg.n_slots, np.int32)
+        check(lib().az_engine_baseline_moves(self.h, {"random": 0, "greedy": 1}[kind], seed, a.ctypes.data))
+        return a
+
+    def root_status(self):
+        G = self.cfg.n_slots
+        pl = np.zeros(G, np.int8); ov = np.zeros(G, np.uint8); wi = np.zeros(G, np.int8); sc = np.zeros(G, np.int32)
+        check(lib().az_engine_root_status(self.h, pl.ctypes.data, ov.ctypes.data, wi.ctypes.data, sc.ctypes.data))
+        return pl, ov.astype(bool), wi, sc
+
     def root_children(self, slot):
         a = np.zeros(65, np.int32); n = np.zeros(65, np.int32); q = np.zeros(65, np.float64); p = np.zeros(65, np.float64)
         k, rn = C.c_int32(), C.c_int32()

@@ -213,11 +213,21 @@ class AlphaZeroTrainer:
     def evaluate(self, iter_idx):
         if not self.config.do_eval:
             return
-        kwargs = {"n_sim": self.config.simulations} if self.config.eval_opponent == "mcts" else {}
         eval_player = AlphaZeroPlayer(n_sim=self.config.simulations, compute_time=self.config.compute_time, nn=self.nn)
-        opponent = PLAYERS_REGISTER[self.config.eval_opponent](**kwargs)
-        arena = Arena(player1=eval_player, player2=opponent, board=BOARDS_REGISTER[self.game](config=self.config))
-        stats = arena.play_games(n_rounds=self.config.eval_episodes, return_stats=True)
+        if self.config.eval_opponent in ("random", "greedy") and self.config.simulations is not None:
+            # all evaluation games at once on the GPU (same stats dict as Arena.play_games)
+            from .arena import BatchedArena
+            c = self.config
+            opponent = PLAYERS_REGISTER[c.eval_opponent]()
+            arena = BatchedArena(self.game, self.nn, opponent=c.eval_opponent, n_sim=c.simulations, seed=self.seed + iter_idx,
+                                 board_size=getattr(c, "board_size", None), board_width=getattr(c, "board_width", 7),
+                                 board_height=getattr(c, "board_height", 6))
+            stats = arena.play_games(n_rounds=c.eval_episodes, return_stats=True)
+        else:
+            kwargs = {"n_sim": self.config.simulations} if self.config.eval_opponent == "mcts" else {}
+            opponent = PLAYERS_REGISTER[self.config.eval_opponent](**kwargs)
+            arena = Arena(player1=eval_player, player2=opponent, board=BOARDS_REGISTER[self.game](config=self.config))
+            stats = arena.play_games(n_rounds=self.config.eval_episodes, return_stats=True)
         for key in ("player1", "player2", "draw"):
             stats.pop(key, None)
         self.eval_results["results"][iter_idx] = {k: dict(v) for k, v in stats.items()}

@@ -142,6 +142,17 @@ int az_engine_play(az_engine *e, const int32_t *h_actions, int32_t n, int32_t *h
 int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_actions, int32_t *h_N, double *h_Q,
                             double *h_P, int32_t *count, int32_t *root_N);
 
+/* ---- arena support: Arena.play_game(s) (arena.py:36-185) for all slots at once -----------
+ * h_sides[g] = +1/-1: the colour this engine searches for in slot g (0 = both colours, self-play).  az_engine_search
+ * then only touches slots where that colour is to move.  az_engine_best_moves = MCT.get_action_probs(temp = 0) for
+ * those slots (-1 elsewhere); az_engine_baseline_moves = RandomPlayer (kind 0) / GreedyPlayer (kind 1)
+ * (players.py:76-123) for the slots where the OTHER colour is to move; az_engine_play applies a move vector
+ * (-1 = none) to the boards and trees; az_engine_root_status reads every slot's position back. */
+int az_engine_set_sides(az_engine *e, const int8_t *h_sides, int32_t n);
+int az_engine_best_moves(az_engine *e, int32_t *h_actions);
+int az_engine_baseline_moves(az_engine *e, int32_t kind, uint32_t seed, int32_t *h_actions);
+int az_engine_root_status(az_engine *e, int8_t *h_players, uint8_t *h_over, int8_t *h_winner, int32_t *h_score);
+
 /* ---- symmetry augmentation on the device ------------------------------------
  * replaces the loop of AlphaZeroTrainer.self_play (trainer.py:275-284) over Sample.create_reflection_twin /
  * create_rotation_twin: every sample with move_idx >= 2 gets its 7 twins (Connect4: 1) in the reference's

@@ -149,3 +149,50 @@ def test_device_augmentation_matches_reference_memory(tag):
     assert [E.TRANSFORM_NAMES[c] for c in m[:, 3]] == [names[c] for c in fx["transformation"][ref]]
     empty = {k: v[:0] for k, v in smp.items()}
     assert E.augment_samples(gid, H, W, empty)["z"].shape[0] == 0
+
+
+def test_baseline_move_kernels_match_host_players():
+    """RandomPlayer / GreedyPlayer on the device: every chosen move is legal; the greedy one is in the host argmax set"""
+    from conftest import TAGS
+    from alphazero_amd import engine as E
+    from alphazero_amd.games.registers import BOARDS_REGISTER
+    from tools import closed_form as cf
+    for tag in ("othello8", "connect4", "tictactoe"):
+        game, gid, H, W, A, n = TAGS[tag]
+        grids, players, _ = O.random_positions(gid, H, W, 3, 40, 600)
+        G = len(players)
+        eng = E.SelfPlayEngine(gid, H, W, n_slots=G, n_sim=1, evaluator=E.EVAL_FAKE, node_capacity=4096, sample_capacity=16)
+        eng.set_roots(grids, players)
+        eng.set_sides(-players)  # the engine's colour is NOT to move -> baseline_moves answers for every slot
+        for kind in ("random", "greedy"):
+            acts = eng.baseline_moves(kind, seed=11)
+            legal = O.batch_legal(gid, H, W, grids, players)
+            assert (acts >= 0).all() and legal[np.arange(G), acts].all(), (tag, kind)
+            if kind == "greedy":
+                kw = {"othello": dict(n=n), "connect4": dict(width=7, height=6), "tictactoe": {}}[game]
+                for i in range(0, G, 7):
+                    b = BOARDS_REGISTER[game](grid=grids[i].reshape(H, W).astype(np.float64), player=int(players[i]), **kw)
+                    sc = {}
+                    for mv in b.get_moves():
+                        c = b.clone(); c.play_move(mv); sc[cf.move_to_action(game, mv, n)] = -c.get_score()
+                    assert sc[int(acts[i])] == max(sc.values()), (tag, i)
+        assert len(set(eng.baseline_moves("random", seed=1)) | set(eng.baseline_moves("random", seed=2))) > 3
+        eng.close()
+
+
+def test_batched_arena():
+    from alphazero_amd.arena import BatchedArena
+    torch.manual_seed(0)
+    net = OthelloNet(n=6).eval()
+    stats = BatchedArena("othello", net, opponent="greedy", n_sim=16, seed=3).play_games(32)
+    n1, n2, d = len(stats["player1"]), len(stats["player2"]), stats["draw"]
+    assert n1 + n2 + d == 32
+    assert sum(stats["player1_starts"].values()) == 16 and sum(stats["player2_starts"].values()) == 16
+    assert all(0 < s <= 36 for s in stats["player1"] + stats["player2"])
+    torch.manual_seed(1)
+    other = OthelloNet(n=6).eval()
+    s2 = BatchedArena("othello", net, opponent=other, n_sim=12, opponent_n_sim=12, seed=5).play_games(16, start_player=1)
+    assert len(s2["player1"]) + len(s2["player2"]) + s2["draw"] == 16 and sum(s2["player2_starts"].values()) == 0
+    s3 = BatchedArena("connect4", __import__("alphazero_amd.games.connect4", fromlist=["Connect4Net"]).Connect4Net(7, 6).eval(),
+                      opponent="random", n_sim=20, seed=1).play_games(24)
+    assert len(s3["player1"]) + len(s3["player2"]) + s3["draw"] == 24
