@@ -10,7 +10,7 @@ AZ_OK, AZ_EINVAL, AZ_EHIP, AZ_ESTATE, AZ_ECAPACITY, AZ_EILLEGAL = 0, -1, -2, -3,
 GAME_IDS = {"othello": 0, "connect4": 1, "tictactoe": 2}
 TIE_LOWEST, TIE_RANDOM = 0, 1
 NOISE_OFF, NOISE_PHILOX, NOISE_HASH = 0, 1, 2
-EVAL_NET, EVAL_FAKE = 0, 1
+EVAL_NET, EVAL_FAKE, EVAL_ROLLOUT = 0, 1, 2
 
 
 class AzError(RuntimeError):

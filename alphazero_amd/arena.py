@@ -61,8 +61,9 @@ class BatchedArena:
     """Arena.play_games (arena.py:119-185) with all rounds played at once on the GPU.
 
     player1 is an AlphaZero player (network `nn`, `n_sim` simulations, no noise, temperature 0: what
-    AlphaZeroTrainer.evaluate builds, trainer.py:421-425); `opponent` is "random", "greedy" or another network
-    (an Arena-compatible extension: evaluation against a previous network).  Returns the reference's stats dict.
+    AlphaZeroTrainer.evaluate builds, trainer.py:421-425) or "mcts" (MCTSPlayer: UCT + random playouts on the device);
+    `opponent` is "random", "greedy", "mcts" or another network (evaluation against a previous network).
+    Returns the reference's stats dict.
     """
 
     def __init__(self, game, nn, opponent="random", n_sim=100, opponent_n_sim=None, seed=0, board_size=None,
@@ -75,10 +76,13 @@ class BatchedArena:
         self.opponent_n_sim = opponent_n_sim if opponent_n_sim is not None else n_sim
 
     def _engine(self, net, G, n_sim, seed):
-        from .engine import NOISE_OFF, TIE_RANDOM, SelfPlayEngine
+        from .engine import EVAL_NET, EVAL_ROLLOUT, NOISE_OFF, TIE_RANDOM, SelfPlayEngine
         plies = 4 * self.H * self.W + 16
-        return SelfPlayEngine(self.gid, self.H, self.W, n_slots=G, n_sim=n_sim, net=net.to_hip(max_batch=G),
-                              dirichlet_alpha=None, dirichlet_epsilon=None, temp_max_step=-1, temp_min_step=0,
+        rollout = isinstance(net, str)
+        if rollout and net != "mcts":
+            raise ValueError(f"player '{net}' has no search tree")
+        return SelfPlayEngine(self.gid, self.H, self.W, n_slots=G, n_sim=n_sim, net=None if rollout else net.to_hip(max_batch=G),
+                              evaluator=EVAL_ROLLOUT if rollout else EVAL_NET, dirichlet_alpha=None, dirichlet_epsilon=None, temp_max_step=-1, temp_min_step=0,
                               tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed, max_plies=plies, sample_capacity=16)
 
     def play_games(self, n_rounds, start_player=None, return_stats=True):
@@ -97,7 +101,7 @@ class BatchedArena:
         e1.set_roots(grids, ones, game_ids=ids)
         e1.set_sides(side1)
         e2 = None
-        if not isinstance(self.opponent, str):
+        if self.opponent == "mcts" or not isinstance(self.opponent, str):
             e2 = self._engine(self.opponent, G, self.opponent_n_sim, self.seed + 1)
             e2.set_roots(grids, ones, game_ids=ids)
             e2.set_sides(-side1)

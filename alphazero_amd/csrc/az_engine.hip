@@ -63,6 +63,8 @@ struct EngDev {
     int G, C, A, max_plies;
     double alpha, eps;
     int tie_mode, noise_mode, tmax, tmin;
+    u32 sim_base;  // simulations already run on the current roots: keeps Philox counters distinct across repeated az_engine_search calls
+    int rollout;  // 1: TreeEval.ROLLOUT (plain UCT + random playouts, mcts.py:38-42, 152-154, 173-180), no network
     u32 seed;
     long long sample_cap;
     u64 *root_p1, *root_m1; int8_t *root_player;
@@ -234,7 +236,7 @@ AZ_D int pick_child_grp(const EngDev &E, int g, const Node *pool, const Node &pa
     for (int r = 0; r < 4; ++r) { mask[r] = grp_ballot(key[r] == best); cnt += __popc(mask[r]); }
     int k = 0;
     if (E.tie_mode == AZ_TIE_RANDOM && cnt > 1) {  // with a single maximum the draw cannot change the result
-        Philox4 rr = az_philox(E.seed, E.game_id[g], (u32)ply, (u32)sim, AZ_P_TIE_SELECT, (u32)depth);
+        Philox4 rr = az_philox(E.seed, E.game_id[g], (u32)ply, (u32)sim + E.sim_base, AZ_P_TIE_SELECT, (u32)depth);
         k = (int)(((u64)rr.x * (u64)cnt) >> 32);
     }
     int rsel = 0, lsel = 0;
@@ -577,6 +579,155 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// TreeEval.ROLLOUT (BASELINE config 1, the reference's default evaluation opponent): one whole simulation per
+// launch -- UCT selection (mcts.py:38-42, 134-135), expansion with a uniformly random child (mcts.py:152-154,
+// 163-165), random playout to the end of the game (mcts.py:173-180), back-propagation (mcts.py:197-223).
+// np.log is restated by az_det_log (as in the CPU oracle).
+// ---------------------------------------------------------------------------------------------
+#define AZ_P_ROLLOUT_EXPAND 6
+#define AZ_P_PLAYOUT 7
+
+AZ_D int pick_child_uct_grp(const EngDev &E, u32 gid, const Node *pool, const Node &parent, int ply, int sim, int depth, int sub, Node &chosen) {
+    const int fc = parent.first, nc = parent.nch;
+    const double lg = az_det_log((double)parent.N);
+    double key[4];
+    int cN[4], cfirst[4];
+    u32 cpack[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        key[r] = -__builtin_inf();
+        cN[r] = 0; cfirst[r] = -1; cpack[r] = 0;
+        int i = r * LPG + sub;
+        if (i < nc) {
+            Node c = load_node(pool + fc + i);
+            key[r] = c.N == 0 ? __builtin_inf() : c.Q + 1.4142135623730951 * sqrt(lg / (double)c.N);
+            cN[r] = c.N; cfirst[r] = c.first;
+            cpack[r] = (u32)c.nch | ((u32)c.act << 8) | ((u32)c.flags << 16) | ((u32)(uint8_t)c.win << 24);
+        }
+    }
+    double best = grp_max(fmax(fmax(key[0], key[1]), fmax(key[2], key[3])));
+    u32 mask[4];
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mask[r] = grp_ballot((r * LPG + sub) < nc && key[r] == best); cnt += __popc(mask[r]); }
+    int k = 0;
+    if (E.tie_mode == AZ_TIE_RANDOM && cnt > 1) {
+        Philox4 rr = az_philox(E.seed, gid, (u32)ply, (u32)sim + E.sim_base, AZ_P_TIE_SELECT, (u32)depth);
+        k = (int)(((u64)rr.x * (u64)cnt) >> 32);
+    }
+    int rsel = 0, lsel = 0;
+    bool found = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int pc = __popc(mask[r]);
+        if (!found) { if (k < pc) { rsel = r; lsel = kth_set_bit(mask[r], k); found = true; } else k -= pc; }
+    }
+    const int vN = rsel == 0 ? cN[0] : (rsel == 1 ? cN[1] : (rsel == 2 ? cN[2] : cN[3]));
+    const int vF = rsel == 0 ? cfirst[0] : (rsel == 1 ? cfirst[1] : (rsel == 2 ? cfirst[2] : cfirst[3]));
+    const u32 vP = rsel == 0 ? cpack[0] : (rsel == 1 ? cpack[1] : (rsel == 2 ? cpack[2] : cpack[3]));
+    chosen.N = __shfl(vN, lsel, LPG);
+    chosen.first = __shfl(vF, lsel, LPG);
+    const u32 pk = (u32)__shfl((int)vP, lsel, LPG);
+    chosen.nch = (uint8_t)(pk & 0xff); chosen.act = (uint8_t)((pk >> 8) & 0xff); chosen.flags = (uint8_t)((pk >> 16) & 0xff);
+    chosen.win = (int8_t)(pk >> 24);
+    chosen.Q = 0.0; chosen.P = 0.0; chosen.parent = 0;
+    return fc + rsel * LPG + lsel;
+}
+
+__global__ __launch_bounds__(256) void k_rollout_step(EngDev E, int sim) {
+    const int g = blockIdx.x * GPB + (threadIdx.x >> 4), sub = threadIdx.x & (LPG - 1);
+    if (g >= E.G || !searches(E, g)) return;
+    const GameDesc &gd = E.gd;
+    Node *pool = pool_of(E, g);
+    const int ply = E.ply[g];
+    const u32 gid = E.game_id[g];
+    int n_nodes = E.n_nodes[g];
+    BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
+    int node = E.root[g];
+    Node cur = load_node(pool + node);
+    int depth = 0, plen = 1;
+    int my_path = sub == 0 ? node : -1;
+    bool reached_new = false;
+    while (cur.flags & F_EXPANDED) {  // mcts.py:132-144
+        Node ch;
+        int c = pick_child_uct_grp(E, gid, pool, cur, ply, sim, depth++, sub, ch);
+        node = c; cur = ch;
+        if (sub == plen) my_path = c;
+        ++plen;
+        az_play_grp(gd, b, cur.act, sub);
+        if (cur.N == 0) { reached_new = true; break; }
+    }
+    int w = 0;
+    bool over = az_status_grp(gd, b, &w, sub);
+    if (!reached_new && !over) {  // mcts.py:146-171 : expand with every legal move, step into a uniformly random child
+        u64 bits = az_legal_bits_grp(gd, b, b.player, sub);
+        const bool pass = (gd.game == AZ_OTHELLO && bits == 0);
+        const int k = pass ? 1 : __popcll(bits);
+        if (n_nodes + k > E.C) { if (sub == 0) { atomicOr(E.err, ERR_NODE_POOL); E.active[g] = 0; } return; }
+        const int fc = n_nodes;
+        if (pass) { if (sub == 0) store_node(pool + fc, fresh_node(gd.A - 1, node, 0.0, 0)); }
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int bit = r * LPG + sub;
+                if ((bits >> bit) & 1ULL) store_node(pool + fc + __popcll(bits & ((1ULL << bit) - 1ULL)), fresh_node(az_bit_to_action(gd, bit), node, 0.0, 0));
+            }
+        }
+        n_nodes += k;
+        if (sub == 0) { pool[node].first = fc; pool[node].nch = (uint8_t)k; pool[node].flags = cur.flags | F_EXPANDED; E.n_nodes[g] = n_nodes; }
+        Philox4 rr = az_philox(E.seed, gid, (u32)ply, (u32)sim + E.sim_base, AZ_P_ROLLOUT_EXPAND, (u32)depth);
+        const int pick = (int)(((u64)rr.x * (u64)k) >> 32);
+        int act;
+        if (pass) act = gd.A - 1;
+        else { u64 m = bits; for (int i = 0; i < pick; ++i) m &= m - 1; act = az_bit_to_action(gd, __ffsll((long long)m) - 1); }
+        node = fc + pick;
+        if (sub == plen) my_path = node;
+        ++plen;
+        az_play_grp(gd, b, act, sub);
+        over = az_status_grp(gd, b, &w, sub);
+    }
+    const int player_to_play = b.player;  // mcts.py:243 : side to move at the selected node
+    for (u32 step = 0; !over; ++step) {    // mcts.py:173-180 : uniformly random playout
+        u64 bits = az_legal_bits_grp(gd, b, b.player, sub);
+        int act;
+        if (gd.game == AZ_OTHELLO && bits == 0) act = gd.A - 1;
+        else {
+            const int k = __popcll(bits);
+            Philox4 rr = az_philox(E.seed, gid, (u32)ply, (u32)sim + E.sim_base, AZ_P_PLAYOUT, step);
+            const int pick = (int)(((u64)rr.x * (u64)k) >> 32);
+            u64 m = bits;
+            for (int i = 0; i < pick; ++i) m &= m - 1;
+            act = az_bit_to_action(gd, __ffsll((long long)m) - 1);
+        }
+        az_play_grp(gd, b, act, sub);
+        over = az_status_grp(gd, b, &w, sub);
+    }
+    // back_propagate along the recorded path
+    const double outcome = (double)w;
+    double reward;
+    if (fabs(outcome) < 1e-4) reward = 0.0;
+    else reward = ((double)player_to_play * outcome > 0.0) ? -fabs(outcome) : fabs(outcome);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (plen <= LPG) {
+        if (sub < plen) {
+            Node n = load_node(pool + my_path);
+            const int up = plen - 1 - sub;
+            const double r = (reward == 0.0) ? 0.0 : ((up & 1) ? -reward : reward);
+            pool[my_path].Q = ((double)n.N * n.Q + r) / (double)(n.N + 1);
+            pool[my_path].N = n.N + 1;
+        }
+    } else {
+        int nd = node;
+        while (nd >= 0) {
+            Node n = load_node(pool + nd);
+            if (sub == 0) { pool[nd].Q = ((double)n.N * n.Q + reward) / (double)(n.N + 1); pool[nd].N = n.N + 1; }
+            nd = n.parent;
+            reward = (reward == 0.0) ? 0.0 : -reward;
+        }
+    }
+}
+
 AZ_D double linear_temp(int step, int tmax, int tmin) {  // schedulers.py:33-40
     if (step <= tmax) return 1.0;
     if (step >= tmin) return 0.0;
@@ -870,6 +1021,7 @@ struct az_engine {
     unsigned long long *h_ctr;  // pinned
     int *h_err;                 // pinned [2] : err, max_nodes
     long long lockstep_iters;
+    u32 sim_base = 0;
 };
 
 int az_make_game_desc(int game, int H, int W, GameDesc *gd) {
@@ -916,7 +1068,7 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
     AZ_REQUIRE(cfg->max_plies > 0 && cfg->sample_capacity > 0, AZ_EINVAL, "max_plies / sample_capacity must be positive");
     AZ_REQUIRE(cfg->temp_min_step >= cfg->temp_max_step, AZ_EINVAL,
                "temp_min_step should be greater than temp_max_step for linear scheduler.");  // schedulers.py:29-30
-    AZ_REQUIRE(cfg->evaluator == AZ_EVAL_FAKE || net != nullptr, AZ_ESTATE, "a network is required for AZ_EVAL_NET");
+    AZ_REQUIRE(cfg->evaluator != AZ_EVAL_NET || net != nullptr, AZ_ESTATE, "a network is required for AZ_EVAL_NET");
     if (cfg->evaluator == AZ_EVAL_NET)
         AZ_REQUIRE(az_net_action_size(net) == gd.A, AZ_EINVAL, "network action size %d != game action size %d",
                    az_net_action_size(net), gd.A);
@@ -926,6 +1078,7 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
     EngDev &d = e->d;
     d.gd = gd; d.G = cfg->n_slots; d.C = cfg->node_capacity; d.A = gd.A; d.max_plies = cfg->max_plies;
     d.alpha = cfg->dirichlet_alpha; d.eps = cfg->dirichlet_epsilon; d.tie_mode = cfg->tie_mode;
+    d.rollout = cfg->evaluator == AZ_EVAL_ROLLOUT ? 1 : 0;
     d.noise_mode = cfg->noise_mode; d.tmax = cfg->temp_max_step; d.tmin = cfg->temp_min_step; d.seed = cfg->seed;
     d.sample_cap = cfg->sample_capacity;
     size_t G = d.G, NC = G * (size_t)d.C, S = (size_t)cfg->sample_capacity;
@@ -971,6 +1124,14 @@ static int forward(az_engine *e, const int *cnt) {
 static int do_search(az_engine *e, int n_sim) {
     EngDev &d = e->d;
     dim3 gg((unsigned)((d.G + GPB - 1) / GPB)), gb(256);
+    d.sim_base = e->sim_base;
+    e->sim_base += (u32)n_sim;
+    if (d.rollout) {  // no network: one launch per simulation
+        for (int s = 0; s < n_sim; ++s) hipLaunchKernelGGL(k_rollout_step, gg, gb, 0, e->stream, d, s);
+        e->lockstep_iters += n_sim;
+        AZ_HIP(hipGetLastError());
+        return AZ_OK;
+    }
     hipLaunchKernelGGL(k_root_prep, gg, gb, 0, e->stream, d, 0, d.G);
     AZ_TRY(forward(e, d.batch_cnt + 2));
     hipLaunchKernelGGL(k_root_init, gg, gb, 0, e->stream, d, 0, d.G);
@@ -1009,6 +1170,7 @@ extern "C" int az_engine_run(az_engine *e, uint32_t first_game_id, int32_t n_gam
     hipLaunchKernelGGL(k_reset_all, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, (u32)first_game_id, (int)n_games);
     long long max_iters = ((long long)n_games / d.G + 2) * (long long)d.max_plies + 8;
     for (long long it = 0; it < max_iters; ++it) {
+        e->sim_base = 0;
         AZ_TRY(do_search(e, e->cfg.n_sim));
         hipLaunchKernelGGL(k_move, grid_for(d.G, TB), dim3(TB), 0, e->stream, d);
         hipLaunchKernelGGL(k_reroot, dim3((unsigned)((d.G + GPB - 1) / GPB)), dim3(256), 0, e->stream, d);
@@ -1050,6 +1212,7 @@ extern "C" int az_engine_samples(az_engine *e, int64_t *n_samples, const int8_t 
 
 extern "C" int az_engine_set_roots(az_engine *e, const int8_t *h_grids, const int8_t *h_players, const uint32_t *h_game_ids,
                                    const int32_t *h_plies, int32_t n_roots) {
+    if (e) e->sim_base = 0;
     AZ_REQUIRE(e && h_grids && h_players, AZ_EINVAL, "null argument");
     EngDev &d = e->d;
     AZ_REQUIRE(n_roots > 0 && n_roots <= d.G, AZ_EINVAL, "n_roots must be in [1, n_slots]");
@@ -1088,6 +1251,7 @@ extern "C" int az_engine_search(az_engine *e, int32_t n_sim) {
 }
 
 extern "C" int az_engine_advance(az_engine *e) {
+    if (e) e->sim_base = 0;
     AZ_REQUIRE(e, AZ_EINVAL, "null argument");
     EngDev &d = e->d;
     // games that end here must not be refilled: cap the queue at what has been started
@@ -1126,6 +1290,7 @@ extern "C" int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_ac
 }
 
 extern "C" int az_engine_play(az_engine *e, const int32_t *h_actions, int32_t n, int32_t *h_status) {
+    if (e) e->sim_base = 0;
     AZ_REQUIRE(e && h_actions && h_status, AZ_EINVAL, "null argument");
     EngDev &d = e->d;
     AZ_REQUIRE(n > 0 && n <= d.G, AZ_EINVAL, "n must be in [1, n_slots]");

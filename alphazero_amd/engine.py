@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (EVAL_FAKE, EVAL_NET, GAME_IDS, NOISE_HASH, NOISE_OFF, NOISE_PHILOX, TIE_LOWEST, TIE_RANDOM,  # noqa: F401
+from ._lib import (EVAL_FAKE, EVAL_NET, EVAL_ROLLOUT, GAME_IDS, NOISE_HASH, NOISE_OFF, NOISE_PHILOX, TIE_LOWEST, TIE_RANDOM,  # noqa: F401
                    EngineCfg, EngineStats, check, lib)
 
 
@@ -144,7 +144,10 @@ class HipNet:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
 
 # ---------------------------------------------------------------------------------------------- engine
@@ -252,4 +255,7 @@ class SelfPlayEngine:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass

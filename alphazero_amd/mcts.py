@@ -1,13 +1,15 @@
 """MCT with the reference's interface (mcts.py:49-269).
 
-* eval_method "neural": the tree lives on the GPU -- one slot of the HIP self-play engine (csrc/az_engine.hip);
-  `search` runs lock-step simulations there, `change_root` re-roots / compacts the device tree.  For many games
-  at once use alphazero_amd.engine.SelfPlayEngine directly; this class is the single-game plugin surface
-  (Arena, interactive play).
-* eval_method "rollout" (plain UCT with random playouts, BASELINE config 1) is host code: it has no network
-  and is the reference's CPU path by definition.
+The tree lives on the GPU -- one slot of the HIP self-play engine (csrc/az_engine.hip): `search` runs the
+simulations there, `change_root` re-roots / compacts the device tree.
+
+* eval_method "neural": PUCT with the policy/value network (lock-step k_step + network forward).
+* eval_method "rollout": plain UCT with random playouts (BASELINE config 1), k_rollout_step -- one launch per
+  simulation, no network.
+
+For many games at once use alphazero_amd.engine.SelfPlayEngine / alphazero_amd.arena.BatchedArena directly;
+this class is the single-game plugin surface (Arena, interactive play).
 """
-import math
 from time import time
 
 import numpy as np
@@ -36,19 +38,6 @@ def _move_of(board, action):
     return (action // w, action % w)
 
 
-class Node:
-    """host-side node, rollout mode only (mcts.py:8-46)"""
-    __slots__ = ("move", "parent", "N", "Q", "children")
-
-    def __init__(self, move, parent):
-        self.move, self.parent, self.N, self.Q, self.children = move, parent, 0, 0, {}
-
-    def UCT(self, c_exploration=math.sqrt(2)):
-        if self.N == 0:
-            return float("inf")
-        return self.Q + c_exploration * np.sqrt(np.log(self.parent.N) / self.N)
-
-
 class MCT:
     def __init__(self, eval_method=None, nn=None, dirichlet_alpha=None, dirichlet_epsilon=None, seed=None):
         self.n_rollouts = 0
@@ -59,9 +48,8 @@ class MCT:
         self.dirichlet_epsilon = dirichlet_epsilon
         if self._nn is not None and self.eval_method != TreeEval.NEURAL:
             raise ValueError(f"A neural network has been set for the MCT but the evaluation method is {self.eval_method}")
-        self.root = Node(None, None)  # rollout mode
         self._seed = int(np.random.randint(0, 2**31 - 1)) if seed is None else int(seed)
-        self._engine = None           # neural mode: device tree
+        self._engine = None           # device tree (one engine slot)
         self._hipnet = None
         self._root_key = None         # (grid bytes, player) of the position the device root stands for
         self._last_board = None
@@ -88,36 +76,26 @@ class MCT:
         start = time()
         if n_sim is None and compute_time is None:
             raise ValueError("MCT.search needs to have either n_sim or compute_time specified.")
-        if self.eval_method == TreeEval.NEURAL:
-            self._sync_device_root(board)
-            if n_sim is not None:
-                self._engine.search(n_sim)
-                self.n_rollouts = n_sim
-            else:
-                while time() - start < compute_time:
-                    self._engine.search(1)
-                    self.n_rollouts += 1
+        self._sync_device_root(board)
+        if n_sim is not None:
+            self._engine.search(n_sim)
+            self.n_rollouts = n_sim
         else:
-            if n_sim is not None:
-                for _ in range(n_sim):
-                    self._rollout_iter(board.clone())
-            else:
-                while time() - start < compute_time:
-                    self._rollout_iter(board.clone())
+            chunk = 1 if self.eval_method == TreeEval.NEURAL else 8
+            while time() - start < compute_time:
+                self._engine.search(chunk)
+                self.n_rollouts += chunk
         self.simulation_time = time() - start
 
     def get_prior_probs(self):
-        if self.eval_method != TreeEval.NEURAL:
-            return {move: None for move in self.root.children}
         a, _, _, p, _ = self._children()
+        if self.eval_method != TreeEval.NEURAL:
+            return {_move_of(self._last_board, int(ai)): None for ai in a}
         return {_move_of(self._last_board, int(ai)): float(pi) for ai, pi in zip(a, p)}
 
     def get_action_probs(self, board, temp=0):
-        if self.eval_method == TreeEval.NEURAL:
-            a, n, _, _, _ = self._children()
-            counts = {_move_of(board, int(ai)): int(ni) for ai, ni in zip(a, n)}
-        else:
-            counts = {move: int(node.N) for move, node in self.root.children.items()}
+        a, n, _, _, _ = self._children()
+        counts = {_move_of(board, int(ai)): int(ni) for ai, ni in zip(a, n)}
         if len(counts) == 0:
             return {board.pass_move: 1.}
         if temp == 0:
@@ -128,40 +106,37 @@ class MCT:
         return {m: v / total for m, v in powered.items()}, counts
 
     def change_root(self, move):
-        if self.eval_method == TreeEval.NEURAL:
-            if self._engine is None or self._root_key is None:
-                return  # no device tree yet: the next search starts from the board it is given
-            b = self._last_board.clone()
-            b.play_move(move)  # raises ValueError for an illegal move, like the engine would
-            self._engine.play([_action_of(self._last_board, move)])
-            self._last_board = b
-            self._root_key = (b.grid.astype(np.int8).tobytes(), int(b.player))
-        elif move in self.root.children:
-            self.root = self.root.children[move]
-            self.root.parent = None
-        else:
-            self.root = Node(None, None)
+        if self._engine is None or self._root_key is None:
+            return  # no device tree yet: the next search starts from the board it is given
+        b = self._last_board.clone()
+        b.play_move(move)  # raises ValueError for an illegal move, like the engine would
+        self._engine.play([_action_of(self._last_board, move)])
+        self._last_board = b
+        self._root_key = (b.grid.astype(np.int8).tobytes(), int(b.player))
 
-    # ------------------------------------------------------------------ neural mode (device tree)
+    # ------------------------------------------------------------------ device tree
     def _children(self):
         if self._engine is None:
             return [], [], [], [], 0
         return self._engine.root_children(0)
 
     def _sync_device_root(self, board):
-        from .engine import EVAL_NET, NOISE_OFF, NOISE_PHILOX, TIE_RANDOM, SelfPlayEngine
-        if self._nn is None:
+        from .engine import EVAL_NET, EVAL_ROLLOUT, NOISE_OFF, NOISE_PHILOX, TIE_RANDOM, SelfPlayEngine
+        neural = self.eval_method == TreeEval.NEURAL
+        if neural and self._nn is None:
             raise ValueError("The MCT has no neural network to evaluate positions with.")
         H, W = board.grid.shape
         if self._engine is None:
-            if self._hipnet is None:
+            if neural and self._hipnet is None:
                 self._hipnet = self._nn.to_hip(max_batch=16)
             noisy = self.dirichlet_alpha is not None and self.dirichlet_epsilon is not None
             self._engine = SelfPlayEngine(_GAME_IDS[board.game], H, W, n_slots=1, n_sim=1, net=self._hipnet,
                                           dirichlet_alpha=self.dirichlet_alpha, dirichlet_epsilon=self.dirichlet_epsilon,
                                           temp_max_step=-1, temp_min_step=0, tie_mode=TIE_RANDOM,
-                                          noise_mode=NOISE_PHILOX if noisy else NOISE_OFF, evaluator=EVAL_NET,
-                                          seed=self._seed, sample_capacity=4 * H * W + 16, max_plies=4 * H * W + 16)
+                                          noise_mode=NOISE_PHILOX if noisy else NOISE_OFF,
+                                          evaluator=EVAL_NET if neural else EVAL_ROLLOUT,
+                                          seed=self._seed, sample_capacity=4 * H * W + 16, max_plies=4 * H * W + 16,
+                                          node_capacity=1 << 21)  # one slot: room for long compute_time searches
             self._plies = 0
         key = (board.grid.astype(np.int8).tobytes(), int(board.player))
         if key != self._root_key:  # tree restarted from an unexplored state (mcts.py:124-125, 231-233)
@@ -169,34 +144,3 @@ class MCT:
                                    game_ids=np.array([np.random.randint(0, 2**31 - 1)], np.uint32))
             self._root_key = key
         self._last_board = board.clone()
-
-    # ------------------------------------------------------------------ rollout mode (host)
-    def _rollout_iter(self, board):
-        node = self.root
-        while node.children:
-            move, node = fair_max(node.children.items(), key=lambda kv: kv[1].UCT())
-            board.play_move(move)
-            if node.N == 0:
-                break
-        else:
-            if not board.is_game_over():
-                for move in board.get_moves():
-                    node.children[move] = Node(move, node)
-                moves = list(node.children)
-                move = moves[np.random.choice(len(moves))]
-                board.play_move(move)
-                node = node.children[move]
-        to_play = board.player
-        while not board.is_game_over():
-            board.play_move(board.get_random_move())
-        outcome = float(board.get_winner())
-        if abs(outcome) < 1e-4:
-            reward = 0
-        else:
-            reward = -abs(outcome) if to_play * outcome > 0 else abs(outcome)
-        while node is not None:
-            node.Q = (node.N * node.Q + reward) / (node.N + 1)
-            node.N += 1
-            node = node.parent
-            reward = -reward
-        self.n_rollouts += 1

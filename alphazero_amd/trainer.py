@@ -214,11 +214,11 @@ class AlphaZeroTrainer:
         if not self.config.do_eval:
             return
         eval_player = AlphaZeroPlayer(n_sim=self.config.simulations, compute_time=self.config.compute_time, nn=self.nn)
-        if self.config.eval_opponent in ("random", "greedy") and self.config.simulations is not None:
+        if self.config.eval_opponent in ("random", "greedy", "mcts") and self.config.simulations is not None:
             # all evaluation games at once on the GPU (same stats dict as Arena.play_games)
             from .arena import BatchedArena
             c = self.config
-            opponent = PLAYERS_REGISTER[c.eval_opponent]()
+            opponent = PLAYERS_REGISTER[c.eval_opponent](**({"n_sim": c.simulations} if c.eval_opponent == "mcts" else {}))
             arena = BatchedArena(self.game, self.nn, opponent=c.eval_opponent, n_sim=c.simulations, seed=self.seed + iter_idx,
                                  board_size=getattr(c, "board_size", None), board_width=getattr(c, "board_width", 7),
                                  board_height=getattr(c, "board_height", 6))

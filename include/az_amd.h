@@ -45,6 +45,7 @@ extern "C" {
 #define AZ_NOISE_MODE_HASH 2   /* closed-form noise from the root board hash (tests) */
 #define AZ_EVAL_NET 0          /* PolicyValueNetwork.evaluate (base.py:357-367) on the HIP network */
 #define AZ_EVAL_FAKE 1         /* closed-form fake network (tests; tools/closed_form.py) */
+#define AZ_EVAL_ROLLOUT 2      /* TreeEval.ROLLOUT: plain UCT with random playouts, no network (mcts.py:38-42, 173-180) */
 
 const char *az_last_error(void);
 int az_version(void);

@@ -748,7 +748,8 @@ static double puct(const orc_mct *t, int c) { /* mcts.py:44-46, c_puct = 1.0 */
 static double uct(const orc_mct *t, int c) { /* mcts.py:38-42, c = sqrt(2) */
     const orc_node *n = &t->nodes[c];
     if (n->N == 0) return INFINITY;
-    return n->Q + sqrt(2.0) * sqrt(log((double)t->nodes[n->parent].N) / (double)n->N);
+    /* np.log restated with the deterministic log shared with the HIP engine (differs from libm by <= 1 ulp) */
+    return n->Q + sqrt(2.0) * sqrt(orc_det_log((double)t->nodes[n->parent].N) / (double)n->N);
 }
 
 static int pick_child(const orc_mct *t, int node, uint32_t depth) {

@@ -1,5 +1,5 @@
 """CPU: Sample / symmetry augmentation of the trainer mirror against the reference's recorded memory (G4),
-rollout-mode MCT (host) and the baseline players."""
+argument checks and the baseline players (the search trees, rollout and neural, live on the GPU: test_gpu_api.py)."""
 import numpy as np
 import pytest
 
@@ -35,23 +35,14 @@ def test_sample_normalize():
     assert s.player == 1 and s.outcome == -1 and np.array_equal(s.state, [[-1., 1.], [0., -1.]])
 
 
-def test_rollout_mct_and_baseline_players():
-    """BASELINE config 1: TicTacToe, rollout MCTS, 100 sims, temp 0 (host path)"""
-    np.random.seed(0)
-    b = BOARDS_REGISTER["tictactoe"]()
-    p = MCTSPlayer(n_sim=100)
-    move, probs, visits, priors = p.get_move(b, temp=0)
-    assert sum(visits.values()) == 100 - 0 and p.mct.root.N == 100 and probs == {move: 1}
-    assert p.get_stats_after_move()["n_rollouts"] == 100 and all(v is None for v in priors.values())
-    p.apply_move(move)
-    assert p.mct.root.parent is None
+def test_baseline_players_and_argument_errors():
     with pytest.raises(ValueError):
         MCTSPlayer()
     with pytest.raises(ValueError):
+        MCTSPlayer(n_sim=10, compute_time=1.0)
+    with pytest.raises(ValueError):
         MCT(eval_method=None, nn=object())
     fx = golden("stats.npz")
-    stats = Arena(MCTSPlayer(n_sim=100), MCTSPlayer(n_sim=100), BOARDS_REGISTER["tictactoe"]()).play_games(30, return_stats=True)
-    assert stats["draw"] / 30 > 0.3  # reference self-play: 62 % draws
     assert abs(int(fx["ttt_rollout_draw"]) / int(fx["ttt_rollout_games"]) - 0.625) < 0.01
     stats = Arena(GreedyPlayer(), RandomPlayer(), BOARDS_REGISTER["othello"](n=6)).play_games(40, return_stats=True)
     assert len(stats["player1"]) > len(stats["player2"])  # report Table 3: greedy beats random

@@ -12,7 +12,7 @@ from alphazero_amd.arena import Arena
 from alphazero_amd.games.othello import OthelloBoard, OthelloConfig, OthelloNet
 from alphazero_amd.games.tictactoe import TicTacToeConfig
 from alphazero_amd.mcts import MCT
-from alphazero_amd.players import AlphaZeroPlayer, GreedyPlayer, RandomPlayer
+from alphazero_amd.players import AlphaZeroPlayer, GreedyPlayer, MCTSPlayer, RandomPlayer
 from alphazero_amd.trainer import AlphaZeroTrainer
 
 pytestmark = pytest.mark.gpu
@@ -196,3 +196,41 @@ def test_batched_arena():
     s3 = BatchedArena("connect4", __import__("alphazero_amd.games.connect4", fromlist=["Connect4Net"]).Connect4Net(7, 6).eval(),
                       opponent="random", n_sim=20, seed=1).play_games(24)
     assert len(s3["player1"]) + len(s3["player2"]) + s3["draw"] == 24
+
+
+def test_rollout_mct_player_on_device():
+    """BASELINE config 1: TicTacToe, rollout MCTS, 100 sims, temp 0 -- the tree and the playouts run on the GPU"""
+    from alphazero_amd.games.registers import BOARDS_REGISTER
+    np.random.seed(0)
+    b = BOARDS_REGISTER["tictactoe"]()
+    p = MCTSPlayer(n_sim=100)
+    move, probs, visits, priors = p.get_move(b, temp=0)
+    assert sum(visits.values()) == 100 and probs == {move: 1} and len(visits) == 9
+    assert p.get_stats_after_move()["n_rollouts"] == 100 and all(v is None for v in priors.values())
+    p.apply_move(move)
+    b.play_move(move)
+    kept = visits[move]
+    _, _, visits2, _ = p.get_move(b, temp=0)
+    assert sum(visits2.values()) == 100 + max(kept - 1, 0)  # tree reuse: the subtree's visits are kept
+    # repeated searches on one root draw fresh random numbers (compute_time mode issues many short searches)
+    q = MCTSPlayer(compute_time=0.05)
+    _, _, v3, _ = q.get_move(BOARDS_REGISTER["tictactoe"](), temp=0)
+    assert sum(v3.values()) == q.get_stats_after_move()["n_rollouts"] and len({n for n in v3.values()}) > 1
+    stats = Arena(MCTSPlayer(n_sim=100), MCTSPlayer(n_sim=100), BOARDS_REGISTER["tictactoe"]()).play_games(30, return_stats=True)
+    assert stats["draw"] / 30 > 0.3  # reference self-play: 62 % draws (tests/golden/stats.npz)
+    stats = Arena(MCTSPlayer(n_sim=50), RandomPlayer(), BOARDS_REGISTER["connect4"](width=7, height=6)).play_games(10, return_stats=True)
+    assert len(stats["player1"]) >= 8
+
+
+def test_batched_arena_rollout_mcts():
+    """all rounds at once: MCTS(rollout) vs random / vs an untrained AlphaZero player"""
+    from alphazero_amd.arena import BatchedArena
+    from alphazero_amd.games.tictactoe import TicTacToeNet
+    st = BatchedArena("tictactoe", "mcts", opponent="random", n_sim=100, seed=3).play_games(200, return_stats=True)
+    n1, n2, d = len(st["player1"]), len(st["player2"]), st["draw"]
+    assert n1 + n2 + d == 200 and n1 > 150 and n2 < 15, (n1, n2, d)
+    st = BatchedArena("tictactoe", "mcts", opponent="mcts", n_sim=100, seed=4).play_games(400, return_stats=True)
+    assert 0.5 < st["draw"] / 400 < 0.75, st["draw"]  # reference: 62.5 % over 2000 games
+    torch.manual_seed(0)
+    st = BatchedArena("tictactoe", TicTacToeNet().eval(), opponent="mcts", n_sim=25, opponent_n_sim=100, seed=5).play_games(64)
+    assert len(st["player1"]) + len(st["player2"]) + st["draw"] == 64

@@ -122,3 +122,17 @@ def test_production_mode_equals_oracle_real_net(tag, n_games, n_sim):
     assert len(got["z"]) == len(ref["z"])
     for k in ("state", "z", "meta", "visits", "pi"):
         assert np.array_equal(got[k], ref[k]), k
+
+
+@pytest.mark.parametrize("tag,n_games,n_sim,slots", [("othello8", 24, 60, 16), ("othello6", 40, 50, 40),
+                                                     ("connect4", 48, 80, 32), ("tictactoe", 128, 100, 64)])
+def test_rollout_mode_equals_oracle(tag, n_games, n_sim, slots):
+    """TreeEval.ROLLOUT (UCT + random playouts, no network) on the device == the oracle, sample for sample"""
+    game, gid, H, W, A, n = TAGS[tag]
+    eng = E.SelfPlayEngine(gid, H, W, n_slots=slots, n_sim=n_sim, evaluator=E.EVAL_ROLLOUT, seed=5, node_capacity=16384,
+                           sample_capacity=n_games * (2 * H * W))
+    got = sort_samples(eng.run(n_games, first_game_id=77))
+    ref = O.selfplay(gid, H, W, n_games, n_sim, ("fake", None), seed=5, first_game_id=77, eval_method=O.EVAL_ROLLOUT)
+    assert eng.stats()["games_done"] == n_games and len(got["z"]) == len(ref["z"])
+    for k in ("state", "z", "meta", "visits", "pi"):
+        assert np.array_equal(got[k], ref[k]), k
