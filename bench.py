@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is `--waves` (1) self-play wave(s): every rank keeps `--games` (4096) Othello 8x8 games resident and
+A "step" is `--waves` (1) self-play wave(s): every rank keeps `--games` (16384) Othello 8x8 games resident and
 plays waves x games of them from the start position to the end at 100 MCTS simulations per move through the
 HIP engine (finished slots are refilled at once)
 (random-init OthelloNet(n=8) under torch.manual_seed(0), Dirichlet noise 0.03/0.25, tau linear(4,4),
@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=4096, help="concurrent games (engine slots) per GPU")
+    ap.add_argument("--games", type=int, default=16384, help="concurrent games (engine slots) per GPU")
     ap.add_argument("--waves", type=int, default=1, help="games per step per GPU = waves x games; finished slots are refilled, "
                                                            "so the ragged end of a wave (games last 60-65 plies) overlaps the next")
     ap.add_argument("--sims", type=int, default=100)
@@ -137,7 +137,7 @@ def main():
         ach = fl[dom] * G / (ms[dom] * 1e-3) / 1e12
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tfile) and G == 4096:
+        if os.path.exists(tfile) and json.load(open(tfile)).get("batch") == G:
             traffic = json.load(open(tfile)).get(["k_trunk", "k_gemm_fc1", "k_gemm_fc2", "k_heads"][dom])
         out["roofline"] = {"bound": "mfma", "kernel": STAGE_NAMES[dom], "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
