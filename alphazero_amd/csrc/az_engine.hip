@@ -1022,6 +1022,7 @@ struct az_engine {
     int *h_err;                 // pinned [2] : err, max_nodes
     long long lockstep_iters;
     u32 sim_base = 0;
+    int active_bound = 0;  // upper bound on the slots still searching (known per ply): caps the network batch, which picks the kernels
 };
 
 int az_make_game_desc(int game, int H, int W, GameDesc *gd) {
@@ -1116,7 +1117,8 @@ static int forward(az_engine *e, const int *cnt) {
         hipLaunchKernelGGL(k_fakenet, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, cnt);
         return AZ_OK;
     }
-    return az_net_forward_dyn(e->net, d.nn_in, cnt, d.G, d.probs, d.value, e->stream);
+    const int cap = e->active_bound > 0 && e->active_bound < d.G ? e->active_bound : d.G;  // leaf rows are compact: count <= searching slots
+    return az_net_forward_dyn(e->net, d.nn_in, cnt, cap, d.probs, d.value, e->stream);
 }
 
 // MCT.search for every active slot: one root-prior pass (mcts.py:231-233; empty unless a slot holds a
@@ -1169,6 +1171,7 @@ extern "C" int az_engine_run(az_engine *e, uint32_t first_game_id, int32_t n_gam
     e->lockstep_iters = 0;
     hipLaunchKernelGGL(k_reset_all, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, (u32)first_game_id, (int)n_games);
     long long max_iters = ((long long)n_games / d.G + 2) * (long long)d.max_plies + 8;
+    e->active_bound = n_games < d.G ? n_games : d.G;
     for (long long it = 0; it < max_iters; ++it) {
         e->sim_base = 0;
         AZ_TRY(do_search(e, e->cfg.n_sim));
@@ -1177,6 +1180,10 @@ extern "C" int az_engine_run(az_engine *e, uint32_t first_game_id, int32_t n_gam
         AZ_TRY(fetch_counters(e));
         AZ_TRY(check_err(e));
         if (e->h_ctr[CTR_GAMES_DONE] >= (unsigned long long)n_games) return AZ_OK;
+        {
+            unsigned long long started = e->h_ctr[CTR_NEXT_GAME] < e->h_ctr[CTR_TOTAL_GAMES] ? e->h_ctr[CTR_NEXT_GAME] : e->h_ctr[CTR_TOTAL_GAMES];
+            e->active_bound = (int)(started - e->h_ctr[CTR_GAMES_DONE]);
+        }
     }
     az_set_error("self-play did not finish within %lld plies", max_iters);
     return AZ_ESTATE;
@@ -1216,6 +1223,7 @@ extern "C" int az_engine_set_roots(az_engine *e, const int8_t *h_grids, const in
     AZ_REQUIRE(e && h_grids && h_players, AZ_EINVAL, "null argument");
     EngDev &d = e->d;
     AZ_REQUIRE(n_roots > 0 && n_roots <= d.G, AZ_EINVAL, "n_roots must be in [1, n_slots]");
+    e->active_bound = n_roots;
     hipLaunchKernelGGL(k_reset_all, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, 0u, (int)n_roots);
     std::vector<u64> p1(n_roots), m1(n_roots);
     std::vector<u32> gid(n_roots);

@@ -39,9 +39,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // instruction writes land on 16 distinct banks
 #define PLANE_STRIDE(x) ((((x) + 30) / 32) * 32 + 1)
 
+#ifdef AZ_PROBE  // diagnostic build only (make PROBE=1): per-phase shader-clock stamps of wave 0 of every block
+__device__ unsigned long long az_probe_buf[8192 * 8];
+#define STAMP(var) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP(var)
+#endif
+
 struct TrunkParams {
     const float *w1f, *b1;       // conv1 B-fragment order [3 k-steps][2][64] (taps 9..11 zero), bias [32]
     const float *wf[3], *cb[3];  // conv2..4 B-fragment order [9][8][2][64], bias [32]
+    const float *w1p;            // conv1, 32x32x2 B-fragment order [5 k-steps][64] (tap 9 zero)
+    const float *wp[3];          // conv2..4, 32x32x2 B-fragment order [9 taps][16 k-steps][64]
 };
 
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -223,19 +232,243 @@ __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_trunk2: the same four layers with TWO boards per wavefront on v_mfma_f32_32x32x2_f32.
+// M = the positions of both boards (tiles of 32 rows), N = the 32 output channels (one tile), K = 9 taps x 32 ic
+// walked tap-major, two input channels per MFMA (lane>>5 selects which).  Against the 16x16x4 version this
+// halves the LDS operand reads and the weight-fragment loads per FLOP, gives conv4 a full tile (2 x 16 rows) and
+// uses the MFMA shape that sustains the higher rate on this chip.  Accumulation order per output is unchanged
+// (bias, then tap-major / ic-minor), so results stay bit-identical.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define A_RING2 3
+
+// PAD = 1 ("same" conv on un-haloed planes): a tap that falls outside the plane is redirected, per lane and per
+// tap, to the plane's spare slot (offset P_IN of every plane, kept zero) -- one address select per tile per TAP, and
+// the MFMA consumes the LDS data directly (a per-k-step value select sat on the LDS -> VALU -> MFMA critical path
+// and cost 12-25 % of conv2).
+template <int P_OUT, int W_OUT, int H_OUT, int IN_W, int IN_PS, int OFF1, int PAD, int MT>
+AZ_D void conv32(const float *in_lds, const float *__restrict__ wf, const float bv, const float (&w0)[16], int lane, f32x16 (&acc)[MT]) {
+    const int m_lane = lane & 31, kk = lane >> 5;
+    int abase[MT], zbase[MT];
+    unsigned vmask[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int r = 32 * mt + m_lane;
+        r = r < 2 * P_OUT ? r : 2 * P_OUT - 1;
+        const int bd = r >= P_OUT ? 1 : 0, p = r - bd * P_OUT;
+        const int y = p / W_OUT, x = p % W_OUT;
+        abase[mt] = bd * OFF1 + kk * IN_PS + y * IN_W + x - PAD * (IN_W + 1);
+        zbase[mt] = bd * OFF1 + kk * IN_PS + (H_OUT + 2 - 2 * PAD) * IN_W;  // the plane's spare zero slot
+        unsigned vm = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int iy = y + t / 3 - PAD, ix = x + t % 3 - PAD;
+            vm |= (unsigned)(iy >= 0 && iy < H_OUT + 2 - 2 * PAD && ix >= 0 && ix < W_OUT + 2 - 2 * PAD) << t;
+        }
+        vmask[mt] = vm;
+    }
+    const float *wl = wf + lane;
+    float bfr[2][16];  // tap 0 arrives preloaded (w0): its L2 latency was paid under the previous layer
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bfr[0][i] = w0[i];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = bv;
+    int tb[2][MT];  // per-tap operand base of every tile (double-buffered: the ring runs ahead across tap boundaries)
+#define TAP_BASE(t, mt) (PAD ? (((vmask[mt] >> (t)) & 1u) ? abase[mt] + ((t) / 3) * IN_W + (t) % 3 : zbase[mt]) : abase[mt] + ((t) / 3) * IN_W + (t) % 3)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { tb[0][mt] = TAP_BASE(0, mt); tb[1][mt] = TAP_BASE(1, mt); }
+    float ar[A_RING2][MT];
+#define CONV_LOAD(c, mt) in_lds[tb[((c) / 16) & 1][mt] + 2 * ((c) % 16) * IN_PS]
+#pragma unroll
+    for (int c = 0; c < A_RING2; ++c)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ar[c][mt] = CONV_LOAD(c, mt);
+#pragma unroll
+    for (int c = 0; c < 144; ++c) {
+        const int tap = c / 16, j = c % 16;
+        if (j == 0 && tap < 8) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bfr[(tap + 1) & 1][i] = wl[((tap + 1) * 16 + i) * 64];
+        }
+        float ac[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ac[mt] = ar[c % A_RING2][mt];
+        if (j == A_RING2 && tap >= 1 && tap < 8) {  // every load of tap-1 has been issued: its base slot takes tap+1
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) tb[(tap + 1) & 1][mt] = TAP_BASE(tap + 1, mt);
+        }
+        if (c + A_RING2 < 144) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ar[c % A_RING2][mt] = CONV_LOAD(c + A_RING2, mt);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // loads stay issued ahead of this step's MFMAs (see conv_mfma)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA32(ac[mt], bfr[tap & 1][j], acc[mt]);
+        // an (empty) ordered use of every accumulator: without it the optimizer, to which an MFMA is a pure call,
+        // sinks whole tile chains below the k-loop towards the epilogue and parks their operands in scratch
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+a"(acc[mt]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef CONV_LOAD
+#undef TAP_BASE
+}
+
+// accumulator register i of a 32x32 tile holds row 8*(i/4) + 4*(lane>>5) + i%4, column lane&31
+template <int P_OUT, int OUT_PS, int OFF1, int MT>
+AZ_D void store_relu_lds32(float *out, int lane, const f32x16 (&acc)[MT]) {
+    const int oc = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = 32 * mt + 8 * (i / 4) + 4 * h + (i % 4);
+            const int bd = r >= P_OUT ? 1 : 0, p = r - bd * P_OUT;
+            const float v = acc[mt][i];
+            if (r < 2 * P_OUT) out[bd * OFF1 + oc * OUT_PS + p] = v > 0.0f ? v : 0.0f;
+        }
+}
+
+// Persistent: one 8-wave workgroup per CU (two waves per SIMD) and every wave walks board pairs handed out by its
+// SIMD's queue; conv1's weights and all biases stay in registers, the next pair's input and the next layer's first
+// weight fragments are fetched under the current layer's MFMAs, so a wave pays global-memory latency once, at its
+// start.  Measured on MI355X, 16384 boards: the MFMA pipes are busy 87 % of the 325 us (the rest: the younger wave
+// of each SIMD runs ~40 % slower than the older one while they share the pipe and finishes its last pair alone;
+// s_setprio can swap the roles but not level them).
+template <int CH, int CW, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_trunk2(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, TrunkParams tp, float *__restrict__ feat) {
+    using G = TrunkGeom<CH, CW>;
+    constexpr int OFF1 = G::WAVE_FLOATS;  // the wave's second board lives right behind the first
+    constexpr int MT2 = (2 * G::P1 + 31) / 32, MT3 = (2 * G::P3 + 31) / 32, MT4 = (2 * G::P4 + 31) / 32;
+    constexpr int NIN = (2 * G::P1 + 63) / 64;
+    if (dyn_count) { int c = *dyn_count; B = c < B ? c : B; }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pairs = (B + 1) >> 1;
+    // Board pairs are handed out by ticket counters in LDS, one queue per SIMD (its two waves share one MFMA pipe, so
+    // every SIMD must get the same work): queue q of block b owns the pairs (4 b + q) + ticket x 4 x blocks.  A
+    // device-wide atomic queue was far slower than the imbalance it removed (hot address: 375 us).
+    int *ticket_ctr = reinterpret_cast<int *>(smem);
+    if (threadIdx.x < 4) ticket_ctr[threadIdx.x] = 0;
+    __syncthreads();  // the only workgroup barrier: the waves are independent from here on
+    const int simd = (__builtin_amdgcn_s_getreg((4 << 11) | (4 << 6) | 4) & 3);  // HW_REG_HW_ID bits [5:4]
+#define NEXT_TICKET(var) { int t_ = 0; if (lane == 0) t_ = atomicAdd(ticket_ctr + simd, 1); var = 4 * (int)blockIdx.x + simd + __builtin_amdgcn_readfirstlane(t_) * 4 * (int)gridDim.x; }
+    int pair;
+    NEXT_TICKET(pair)
+    if (pair >= pairs) return;
+    const int m_lane = lane & 31, kk = lane >> 5;
+    float xin[NIN];
+#define LOAD_INPUT(pr)                                                                            \
+    _Pragma("unroll") for (int u = 0; u < NIN; ++u) {                                             \
+        const int q = lane + 64 * u;                                                              \
+        const size_t idx = (size_t)(pr) * (2 * G::P1) + q;                                        \
+        xin[u] = (q < 2 * G::P1 && idx < (size_t)B * G::P1) ? in[idx] : 0.0f;                     \
+    }
+#define LOAD_W0(ptr) _Pragma("unroll") for (int i = 0; i < 16; ++i) w0[i] = (ptr)[lane + i * 64];
+    LOAD_INPUT(pair)
+    float w1[5], w0[16];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) w1[s5] = tp.w1p[s5 * 64 + lane];
+    const float bv1 = tp.b1[m_lane], bv2 = tp.cb[0][m_lane], bv3 = tp.cb[1][m_lane], bv4 = tp.cb[2][m_lane];
+    LOAD_W0(tp.wp[0])
+    float *inp = smem + 16 + wave * 2 * G::WAVE_FLOATS;  // 64 bytes in front hold the queues
+    float *act = inp + G::INP;
+    for (int i = lane; i < 2 * G::WAVE_FLOATS; i += 64) if (i % G::WAVE_FLOATS < G::INP) inp[i] = 0.0f;
+    act[kk * OFF1 + m_lane * G::PS + G::P1] = 0.0f;  // every plane's spare slot: where conv2's out-of-plane taps read
+    LDS_FENCE();
+    while (true) {
+        int nxt;
+        NEXT_TICKET(nxt)
+        // the per-lane LDS addresses below are loop invariants; hoisted out of this loop they would all stay live
+        // (hundreds of registers, spills) -- an opaque copy of the lane id keeps them inside the round
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        ln &= 63;  // gives the value range back (folds the tile bounds checks)
+        const int b0 = 2 * pair;
+        const bool two = b0 + 1 < B;
+#pragma unroll
+        for (int u = 0; u < NIN; ++u) {
+            const int q = ln + 64 * u;
+            const int bd = q >= G::P1 ? 1 : 0, p = q - bd * G::P1;
+            if (q < 2 * G::P1) inp[bd * OFF1 + (p / CW + 1) * G::PW + (p % CW) + 1] = xin[u];
+        }
+        if (nxt < pairs) { LOAD_INPUT(nxt) }  // consumed at the top of the next round
+        LDS_FENCE();
+        {  // conv1 1->32, pad 1, as a K = 10 product: taps 0..8, tap 9 carries zero weights
+            f32x16 acc[MT2];
+            int pbase[MT2];
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                int r = 32 * mt + (ln & 31);
+                r = r < 2 * G::P1 ? r : 2 * G::P1 - 1;
+                const int bd = r >= G::P1 ? 1 : 0, p = r - bd * G::P1;
+                pbase[mt] = bd * OFF1 + (p / CW) * G::PW + (p % CW);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][i] = bv1;
+            }
+#pragma unroll
+            for (int s5 = 0; s5 < 5; ++s5) {
+                int tap = 2 * s5 + (ln >> 5);
+                tap = tap < 9 ? tap : 8;  // finite operand for the zero-weight column
+                const int toff = (tap / 3) * G::PW + tap % 3;
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) acc[mt] = MFMA32(inp[pbase[mt] + toff], w1[s5], acc[mt]);
+            }
+            store_relu_lds32<G::P1, G::PS, OFF1, MT2>(act, ln, acc);
+        }
+        LDS_FENCE();
+        {  // conv2 32->32, pad 1
+            f32x16 acc[MT2];
+            conv32<G::P1, CW, CH, CW, G::PS, OFF1, 1, MT2>(act, tp.wp[0], bv2, w0, ln, acc);
+            LOAD_W0(tp.wp[1])
+            LDS_FENCE();
+            store_relu_lds32<G::P1, G::PS, OFF1, MT2>(act, ln, acc);
+        }
+        LDS_FENCE();
+        {  // conv3 32->32, valid
+            f32x16 acc[MT3];
+            conv32<G::P3, G::W3, G::H3, CW, G::PS, OFF1, 0, MT3>(act, tp.wp[1], bv3, w0, ln, acc);
+            LOAD_W0(tp.wp[2])
+            LDS_FENCE();
+            store_relu_lds32<G::P3, G::PS, OFF1, MT3>(act, ln, acc);
+        }
+        LDS_FENCE();
+        {  // conv4 32->32, valid -> flattened NCHW features
+            f32x16 acc[MT4];
+            conv32<G::P4, G::W4, G::H4, G::W3, G::PS, OFF1, 0, MT4>(act, tp.wp[2], bv4, w0, ln, acc);
+            LOAD_W0(tp.wp[0])
+            const int oc = ln & 31, h = ln >> 5;
+#pragma unroll
+            for (int mt = 0; mt < MT4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = 32 * mt + 8 * (i / 4) + 4 * h + (i % 4);
+                    const int bd = r >= G::P4 ? 1 : 0, p = r - bd * G::P4;
+                    const float v = acc[mt][i];
+                    if (r < 2 * G::P4 && (bd == 0 || two)) feat[(size_t)(b0 + bd) * (NCH * G::P4) + oc * G::P4 + p] = v > 0.0f ? v : 0.0f;
+                }
+        }
+#ifdef AZ_PROBE
+        for (int i = 0; i < 8; ++i) tacc[i] += ts[i + 1] - ts[i];
+        if (lane == 0 && blockIdx.x < 256 && progress / 4 <= 4) az_probe_buf[((size_t)blockIdx.x * 8 + wave) * 4 + (progress - 1) / 4] = __builtin_amdgcn_s_memrealtime() - rt0;
+#endif
+        pair = nxt;
+        if (pair >= pairs) break;
+    }
+#undef NEXT_TICKET
+#undef LOAD_INPUT
+#undef LOAD_W0
+}
+
 // C[M][N] = act(A[M][K] * Bw[K][N] + bias[N]);  K % 32 == 0, N % BN == 0.
 // f32 MFMA 32x32x2 (sustains ~150 TFLOP/s from a single in-place accumulator chain on this chip; the
 // 16x16x4 shape cycling over many accumulators measured 10-25 % lower: tools/micro/mfma_peak2.hip).
 // LDS double buffer, BK = 32, one barrier per K tile; the global loads of tile t+2 are issued while
 // tile t is computed (two register staging sets); fragment reads run one k-step ahead of the MFMAs.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#ifdef AZ_PROBE  // diagnostic build only (make PROBE=1): per-phase shader-clock stamps of wave 0 of every block
-__device__ unsigned long long az_probe_buf[8192 * 8];
-#define STAMP(var) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define STAMP(var)
-#endif
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 template <int BM, int BN, int WM, int WN, bool RELU, int KT>
 __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const float *__restrict__ Bw,
@@ -627,6 +860,8 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
 #define NA(field, cnt) if (rc == AZ_OK) { rc = net_alloc(n, &p, (cnt)); field = p; }
         NA(n->tp.w1f, 3 * 2 * 64) NA(n->tp.b1, NCH)
         for (int l = 0; l < 3; ++l) { NA(n->tp.wf[l], 9 * 8 * 2 * 64) NA(n->tp.cb[l], NCH) }
+        NA(n->tp.w1p, 5 * 64)
+        for (int l = 0; l < 3; ++l) { NA(n->tp.wp[l], 9 * 16 * 64) }
         NA(n->fc1w, (size_t)n->FIN * n->F1) NA(n->fc1b, n->F1) NA(n->fc2w, (size_t)n->F1 * n->F2) NA(n->fc2b, n->F2)
         NA(n->hw, (size_t)n->F2 * n->NH) NA(n->hb, n->NH)
         NA(n->feat, (size_t)max_batch * n->FIN) NA(n->h1, (size_t)max_batch * n->F1) NA(n->h2, (size_t)max_batch * n->F2)
@@ -736,6 +971,14 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
                         if (t < 9) fw[(sidx * 2 + nt) * 64 + lane] = (float)((double)(*w)[oc * 9 + t] * s[oc]);
                     }
             AZ_TRY(upload((float *)n->tp.w1f, fw, st)); AZ_TRY(upload((float *)n->tp.b1, fb, st));
+            // 32x32x2 B-fragment order [k-step s][lane] = W'[oc = lane&31][tap = 2s + (lane>>5)], 0 for tap 9
+            std::vector<float> fp(5 * 64, 0.0f);
+            for (int sidx = 0; sidx < 5; ++sidx)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int oc = lane & 31, t = 2 * sidx + (lane >> 5);
+                    if (t < 9) fp[sidx * 64 + lane] = (float)((double)(*w)[oc * 9 + t] * s[oc]);
+                }
+            AZ_TRY(upload((float *)n->tp.w1p, fp, st));
         } else {
             // MFMA B-fragment order: [tap][j][nt][lane] = W'[oc = nt*16 + (lane&15)][ic = 4j + (lane>>4)][tap]
             std::vector<float> fw(9 * 8 * 2 * 64);
@@ -747,6 +990,15 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
                             fw[((t * 8 + j) * 2 + nt) * 64 + lane] = (float)((double)(*w)[(oc * NCH + ic) * 9 + t] * s[oc]);
                         }
             AZ_TRY(upload((float *)n->tp.wf[l - 1], fw, st)); AZ_TRY(upload((float *)n->tp.cb[l - 1], fb, st));
+            // 32x32x2 B-fragment order: [tap][j][lane] = W'[oc = lane&31][ic = 2j + (lane>>5)][tap]
+            std::vector<float> fp(9 * 16 * 64);
+            for (int t = 0; t < 9; ++t)
+                for (int j = 0; j < 16; ++j)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        int oc = lane & 31, ic = 2 * j + (lane >> 5);
+                        fp[(t * 16 + j) * 64 + lane] = (float)((double)(*w)[(oc * NCH + ic) * 9 + t] * s[oc]);
+                    }
+            AZ_TRY(upload((float *)n->tp.wp[l - 1], fp, st));
         }
     }
     {
@@ -784,7 +1036,32 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
 }
 
 template <int CH, int CW>
+static int launch_trunk2(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
+    using G = TrunkGeom<CH, CW>;
+    constexpr int WPB = 8;  // one workgroup per CU: two waves per SIMD, two boards per wave
+    constexpr int lds_bytes = 64 + WPB * 2 * G::WAVE_FLOATS * 4;
+    static_assert(lds_bytes <= 160 * 1024, "k_trunk2 workgroup does not fit the CU's LDS");
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t pr;
+        int dev = 0;
+        AZ_HIP(hipGetDevice(&dev));
+        AZ_HIP(hipGetDeviceProperties(&pr, dev));
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk2<CH, CW, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        n_cu = pr.multiProcessorCount;
+    }
+    const int pairs = (B + 1) / 2, want = (pairs + 3) / 4;
+    hipLaunchKernelGGL((k_trunk2<CH, CW, WPB>), dim3(want < n_cu ? want : n_cu), dim3(64 * WPB), lds_bytes, st, in, B, dyn, n->tp, n->feat);
+    return AZ_OK;
+}
+
+static bool trunk_v1() { static int v = -1; if (v < 0) { const char *e = getenv("AZ_TRUNK_V1"); v = (e && atoi(e)) ? 1 : 0; } return v == 1; }
+
+template <int CH, int CW>
 static int launch_trunk(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
+    // two boards per wave on 32x32x2 pays from ~4096 boards up (16384: 325 vs 331 us); below that the one-board-
+    // per-wave kernel fills the chip better (2048: 45 vs 77 us).  AZ_TRUNK_V1=1 forces the latter.
+    if (!trunk_v1() && B >= 4096) return launch_trunk2<CH, CW>(n, in, B, dyn, st);
     using G = TrunkGeom<CH, CW>;
     static bool attr_set = false;
     static int lds_bytes = G::LDS_BYTES;

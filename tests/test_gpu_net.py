@@ -67,3 +67,24 @@ def test_full_batch_and_ragged():
     assert np.array_equal(pf.cpu().numpy()[idx], op) and np.array_equal(vf.cpu().numpy()[idx], ov)
     with pytest.raises(ValueError):
         hnet.forward(torch.zeros((5000, 64), device="cuda"))
+
+
+@pytest.mark.parametrize("tag", ["othello8", "othello6", "connect4"])
+def test_large_batch_kernel_equals_small_batch_kernel(tag):
+    """from 4096 boards up the trunk runs two boards per wave on 32x32x2 MFMA (k_trunk2), below that one board per
+    wave on 16x16x4: same accumulation order, so the same boards must give the same bits in either -- odd and ragged
+    batch sizes included (the small-batch results are the ones checked against the oracle above)"""
+    game, gid, H, W, A, n = TAGS[tag]
+    fx, sd, onet, _ = nets(tag)
+    hnet = E.HipNet(gid, H, W, sd, max_batch=9000)
+    grids, players, _ = O.random_positions(gid, H, W, 11, 40, 1200)
+    canon = torch.as_tensor((grids * players[:, None]).astype(np.float32), device="cuda")
+    n0 = canon.shape[0]
+    p_ref, v_ref = hnet.forward(canon)  # < 4096 rows: one board per wave
+    op, ov = onet.forward(canon.cpu().numpy()[:200])
+    assert np.array_equal(p_ref.cpu().numpy()[:200], op) and np.array_equal(v_ref.cpu().numpy()[:200], ov)
+    for B in (4096, 4099, 6001, 9000):
+        idx = torch.arange(B, device="cuda") % n0
+        idx = (idx * 7 + 3) % n0  # not the same neighbour pairs in every pass
+        p, v = hnet.forward(canon[idx].contiguous())
+        assert torch.equal(p, p_ref[idx]) and torch.equal(v, v_ref[idx]), (tag, B)
