@@ -244,93 +244,146 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define A_RING2 3
 
+// Tiling of a layer's 2 x P_OUT output rows: MT tiles of 32 rows on 32x32x2 and, when at most 16 rows are left
+// over, one 16-row tile on 16x16x4 (two 16-wide channel tiles) instead of a fourth-empty 32-row tile -- Othello 8x8
+// conv3: 72 rows = 2 x 32 + 8 -> 80 row-slots issued instead of 96.
+template <int P_OUT>
+struct ConvPlan {
+    static constexpr int ROWS = 2 * P_OUT, REM = ROWS % 32;
+    static constexpr bool R16 = REM > 0 && REM <= 16;
+    static constexpr int MT = ROWS / 32 + ((REM > 16) ? 1 : 0);
+    static constexpr int MTA = MT > 0 ? MT : 1;  // array extent
+};
+
 // PAD = 1 ("same" conv on un-haloed planes): a tap that falls outside the plane is redirected, per lane and per
 // tap, to the plane's spare slot (offset P_IN of every plane, kept zero) -- one address select per tile per TAP, and
 // the MFMA consumes the LDS data directly (a per-k-step value select sat on the LDS -> VALU -> MFMA critical path
 // and cost 12-25 % of conv2).
-template <int P_OUT, int W_OUT, int H_OUT, int IN_W, int IN_PS, int OFF1, int PAD, int MT>
-AZ_D void conv32(const float *in_lds, const float *__restrict__ wf, const float bv, const float (&w0)[16], int lane, f32x16 (&acc)[MT]) {
+//   wf  : 32x32x2 B fragments [9 taps][16 k-steps][64];  w0 = tap 0, preloaded by the caller
+//   wf16: 16x16x4 B fragments [9 taps][8 k-steps][2 channel tiles][64] (only read when the plan has a 16-row tile)
+template <int P_OUT, int W_OUT, int H_OUT, int IN_W, int IN_PS, int OFF1, int PAD>
+AZ_D void conv32(const float *in_lds, const float *__restrict__ wf, const float *__restrict__ wf16, const float bv, const float (&bv16)[2],
+                 const float (&w0)[16], const float (&w16)[16], int lane, f32x16 (&acc)[ConvPlan<P_OUT>::MTA], f32x4 (&acc16)[2]) {
+    using PL = ConvPlan<P_OUT>;
+    constexpr int MT = PL::MT, MTA = PL::MTA;
+    constexpr bool R16 = PL::R16;
     const int m_lane = lane & 31, kk = lane >> 5;
-    int abase[MT], zbase[MT];
-    unsigned vmask[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int r = 32 * mt + m_lane;
-        r = r < 2 * P_OUT ? r : 2 * P_OUT - 1;
-        const int bd = r >= P_OUT ? 1 : 0, p = r - bd * P_OUT;
-        const int y = p / W_OUT, x = p % W_OUT;
-        abase[mt] = bd * OFF1 + kk * IN_PS + y * IN_W + x - PAD * (IN_W + 1);
-        zbase[mt] = bd * OFF1 + kk * IN_PS + (H_OUT + 2 - 2 * PAD) * IN_W;  // the plane's spare zero slot
-        unsigned vm = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            int iy = y + t / 3 - PAD, ix = x + t % 3 - PAD;
-            vm |= (unsigned)(iy >= 0 && iy < H_OUT + 2 - 2 * PAD && ix >= 0 && ix < W_OUT + 2 - 2 * PAD) << t;
-        }
-        vmask[mt] = vm;
+    int abase[MTA], zbase[MTA];
+    unsigned vmask[MTA];
+#define ROW_SETUP(row, kplane, ab, zb, vm_out)                                                                   \
+    {                                                                                                            \
+        int r_ = (row);                                                                                          \
+        r_ = r_ < 2 * P_OUT ? r_ : 2 * P_OUT - 1;                                                                \
+        const int bd_ = r_ >= P_OUT ? 1 : 0, p_ = r_ - bd_ * P_OUT;                                              \
+        const int y_ = p_ / W_OUT, x_ = p_ % W_OUT;                                                              \
+        ab = bd_ * OFF1 + (kplane) * IN_PS + y_ * IN_W + x_ - PAD * (IN_W + 1);                                  \
+        zb = bd_ * OFF1 + (kplane) * IN_PS + (H_OUT + 2 - 2 * PAD) * IN_W; /* the plane's spare zero slot */     \
+        unsigned vm_ = 0;                                                                                        \
+        _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) {                                                       \
+            int iy_ = y_ + t_ / 3 - PAD, ix_ = x_ + t_ % 3 - PAD;                                                \
+            vm_ |= (unsigned)(iy_ >= 0 && iy_ < H_OUT + 2 - 2 * PAD && ix_ >= 0 && ix_ < W_OUT + 2 - 2 * PAD) << t_; \
+        }                                                                                                        \
+        vm_out = vm_;                                                                                            \
     }
-    const float *wl = wf + lane;
-    float bfr[2][16];  // tap 0 arrives preloaded (w0): its L2 latency was paid under the previous layer
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bfr[0][i] = w0[i];
+    for (int mt = 0; mt < MT; ++mt) ROW_SETUP(32 * mt + m_lane, kk, abase[mt], zbase[mt], vmask[mt])
+    int abase16 = 0, zbase16 = 0;
+    unsigned vmask16 = 0;
+    if (R16) ROW_SETUP(32 * MT + (lane & 15), lane >> 4, abase16, zbase16, vmask16)
+#undef ROW_SETUP
+    const float *wl = wf + lane, *wl16 = wf16 + lane;
+    float bfr[2][16], b16[2][16];  // tap 0 arrives preloaded: its L2 latency was paid under the previous layer
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { bfr[0][i] = w0[i]; if (R16) b16[0][i] = w16[i]; }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = bv;
-    int tb[2][MT];  // per-tap operand base of every tile (double-buffered: the ring runs ahead across tap boundaries)
-#define TAP_BASE(t, mt) (PAD ? (((vmask[mt] >> (t)) & 1u) ? abase[mt] + ((t) / 3) * IN_W + (t) % 3 : zbase[mt]) : abase[mt] + ((t) / 3) * IN_W + (t) % 3)
+    if (R16) { acc16[0] = (f32x4){bv16[0], bv16[0], bv16[0], bv16[0]}; acc16[1] = (f32x4){bv16[1], bv16[1], bv16[1], bv16[1]}; }
+    int tb[2][MTA], tb16[2] = {0, 0};  // per-tap operand bases (double-buffered: the rings run ahead across tap boundaries)
+#define TAP_OFF(t) (((t) / 3) * IN_W + (t) % 3)
+#define TAP_BASE(t, mt) (PAD ? (((vmask[mt] >> (t)) & 1u) ? abase[mt] + TAP_OFF(t) : zbase[mt]) : abase[mt] + TAP_OFF(t))
+#define TAP_BASE16(t) (PAD ? (((vmask16 >> (t)) & 1u) ? abase16 + TAP_OFF(t) : zbase16) : abase16 + TAP_OFF(t))
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { tb[0][mt] = TAP_BASE(0, mt); tb[1][mt] = TAP_BASE(1, mt); }
-    float ar[A_RING2][MT];
+    if (R16) { tb16[0] = TAP_BASE16(0); tb16[1] = TAP_BASE16(1); }
+    float ar[A_RING2][MTA], ar16[2] = {0.0f, 0.0f};
 #define CONV_LOAD(c, mt) in_lds[tb[((c) / 16) & 1][mt] + 2 * ((c) % 16) * IN_PS]
+#define CONV_LOAD16(c16) in_lds[tb16[((c16) / 8) & 1] + 4 * ((c16) % 8) * IN_PS]
 #pragma unroll
     for (int c = 0; c < A_RING2; ++c)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) ar[c][mt] = CONV_LOAD(c, mt);
+    if (R16) { ar16[0] = CONV_LOAD16(0); ar16[1] = CONV_LOAD16(1); }
 #pragma unroll
     for (int c = 0; c < 144; ++c) {
         const int tap = c / 16, j = c % 16;
         if (j == 0 && tap < 8) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bfr[(tap + 1) & 1][i] = wl[((tap + 1) * 16 + i) * 64];
+            for (int i = 0; i < 16; ++i) {
+                bfr[(tap + 1) & 1][i] = wl[((tap + 1) * 16 + i) * 64];
+                if (R16) b16[(tap + 1) & 1][i] = wl16[((tap + 1) * 16 + i) * 64];
+            }
         }
-        float ac[MT];
+        float ac[MTA], a16 = 0.0f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) ac[mt] = ar[c % A_RING2][mt];
+        if (R16 && j % 2 == 0) a16 = ar16[(c / 2) % 2];
         if (j == A_RING2 && tap >= 1 && tap < 8) {  // every load of tap-1 has been issued: its base slot takes tap+1
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) tb[(tap + 1) & 1][mt] = TAP_BASE(tap + 1, mt);
+            if (R16) tb16[(tap + 1) & 1] = TAP_BASE16(tap + 1);
         }
         if (c + A_RING2 < 144) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) ar[c % A_RING2][mt] = CONV_LOAD(c + A_RING2, mt);
         }
+        if (R16 && j % 2 == 0 && c / 2 + 2 < 72) ar16[(c / 2) % 2] = CONV_LOAD16(c / 2 + 2);
         __builtin_amdgcn_sched_barrier(0);  // loads stay issued ahead of this step's MFMAs (see conv_mfma)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA32(ac[mt], bfr[tap & 1][j], acc[mt]);
+        if (R16 && j % 2 == 0) {  // one 16x16x4 k-step (4 input channels) per two 32x32x2 k-steps (2 each)
+            acc16[0] = MFMA(a16, b16[tap & 1][j + 0], acc16[0]);
+            acc16[1] = MFMA(a16, b16[tap & 1][j + 1], acc16[1]);
+        }
         // an (empty) ordered use of every accumulator: without it the optimizer, to which an MFMA is a pure call,
         // sinks whole tile chains below the k-loop towards the epilogue and parks their operands in scratch
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+a"(acc[mt]));
+        if (R16 && j % 2 == 0) { asm volatile("" : "+a"(acc16[0])); asm volatile("" : "+a"(acc16[1])); }
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef CONV_LOAD
+#undef CONV_LOAD16
 #undef TAP_BASE
+#undef TAP_BASE16
+#undef TAP_OFF
 }
 
-// accumulator register i of a 32x32 tile holds row 8*(i/4) + 4*(lane>>5) + i%4, column lane&31
-template <int P_OUT, int OUT_PS, int OFF1, int MT>
-AZ_D void store_relu_lds32(float *out, int lane, const f32x16 (&acc)[MT]) {
-    const int oc = lane & 31, h = lane >> 5;
+// Epilogue: ReLU and hand every accumulator element to `sink(row, oc, value)`, row < 2 * P_OUT.
+// 32x32 tile register i holds row 8*(i/4) + 4*(lane>>5) + i%4, column lane&31; 16x16 tile register r holds row
+// 4*(lane>>4) + r, column lane&15.
+template <int P_OUT, typename SINK>
+AZ_D void conv_epilogue(int lane, const f32x16 (&acc)[ConvPlan<P_OUT>::MTA], const f32x4 (&acc16)[2], SINK sink) {
+    using PL = ConvPlan<P_OUT>;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < PL::MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int r = 32 * mt + 8 * (i / 4) + 4 * h + (i % 4);
-            const int bd = r >= P_OUT ? 1 : 0, p = r - bd * P_OUT;
+            const int r = 32 * mt + 8 * (i / 4) + 4 * (lane >> 5) + (i % 4);
             const float v = acc[mt][i];
-            if (r < 2 * P_OUT) out[bd * OFF1 + oc * OUT_PS + p] = v > 0.0f ? v : 0.0f;
+            if (r < 2 * P_OUT) sink(r, lane & 31, v > 0.0f ? v : 0.0f);
         }
+    if (PL::R16) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = 32 * PL::MT + 4 * (lane >> 4) + r4;
+                const float v = acc16[nt][r4];
+                if (r < 2 * P_OUT) sink(r, nt * 16 + (lane & 15), v > 0.0f ? v : 0.0f);
+            }
+    }
 }
 
 // Persistent: one 8-wave workgroup per CU (two waves per SIMD) and every wave walks board pairs handed out by its
@@ -342,8 +395,11 @@ AZ_D void store_relu_lds32(float *out, int lane, const f32x16 (&acc)[MT]) {
 template <int CH, int CW, int WPB>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_trunk2(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, TrunkParams tp, float *__restrict__ feat) {
     using G = TrunkGeom<CH, CW>;
+    using PL2 = ConvPlan<G::P1>;
+    using PL3 = ConvPlan<G::P3>;
+    using PL4 = ConvPlan<G::P4>;
     constexpr int OFF1 = G::WAVE_FLOATS;  // the wave's second board lives right behind the first
-    constexpr int MT2 = (2 * G::P1 + 31) / 32, MT3 = (2 * G::P3 + 31) / 32, MT4 = (2 * G::P4 + 31) / 32;
+    constexpr int MT1 = (2 * G::P1 + 31) / 32;  // conv1 (K = 10) simply runs whole 32-row tiles
     constexpr int NIN = (2 * G::P1 + 63) / 64;
     if (dyn_count) { int c = *dyn_count; B = c < B ? c : B; }
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -368,13 +424,21 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
         const size_t idx = (size_t)(pr) * (2 * G::P1) + q;                                        \
         xin[u] = (q < 2 * G::P1 && idx < (size_t)B * G::P1) ? in[idx] : 0.0f;                     \
     }
-#define LOAD_W0(ptr) _Pragma("unroll") for (int i = 0; i < 16; ++i) w0[i] = (ptr)[lane + i * 64];
+#define LOAD_W0(l) { _Pragma("unroll") for (int i = 0; i < 16; ++i) w0[i] = tp.wp[l][lane + i * 64]; }
+#define LOAD_W16(l, PLAN) { if (PLAN::R16) { _Pragma("unroll") for (int i = 0; i < 16; ++i) w16[i] = tp.wf[l][lane + i * 64]; } }
     LOAD_INPUT(pair)
-    float w1[5], w0[16];
+    float w1[5], w0[16], w16[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w16[i] = 0.0f;
 #pragma unroll
     for (int s5 = 0; s5 < 5; ++s5) w1[s5] = tp.w1p[s5 * 64 + lane];
     const float bv1 = tp.b1[m_lane], bv2 = tp.cb[0][m_lane], bv3 = tp.cb[1][m_lane], bv4 = tp.cb[2][m_lane];
-    LOAD_W0(tp.wp[0])
+    float bq2[2] = {0.0f, 0.0f}, bq3[2] = {0.0f, 0.0f}, bq4[2] = {0.0f, 0.0f};  // biases in the 16x16 tiles' column order
+    if (PL2::R16) { bq2[0] = tp.cb[0][lane & 15]; bq2[1] = tp.cb[0][16 + (lane & 15)]; }
+    if (PL3::R16) { bq3[0] = tp.cb[1][lane & 15]; bq3[1] = tp.cb[1][16 + (lane & 15)]; }
+    if (PL4::R16) { bq4[0] = tp.cb[2][lane & 15]; bq4[1] = tp.cb[2][16 + (lane & 15)]; }
+    LOAD_W0(0)
+    LOAD_W16(0, PL2)
     float *inp = smem + 16 + wave * 2 * G::WAVE_FLOATS;  // 64 bytes in front hold the queues
     float *act = inp + G::INP;
     for (int i = lane; i < 2 * G::WAVE_FLOATS; i += 64) if (i % G::WAVE_FLOATS < G::INP) inp[i] = 0.0f;
@@ -398,11 +462,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
         }
         if (nxt < pairs) { LOAD_INPUT(nxt) }  // consumed at the top of the next round
         LDS_FENCE();
+        auto to_lds = [&](int P_OUT) {
+            return [=](int r, int oc, float v) { const int bd = r >= P_OUT ? 1 : 0; act[bd * OFF1 + oc * G::PS + (r - bd * P_OUT)] = v; };
+        };
         {  // conv1 1->32, pad 1, as a K = 10 product: taps 0..8, tap 9 carries zero weights
-            f32x16 acc[MT2];
-            int pbase[MT2];
+            f32x16 acc[MT1];
+            int pbase[MT1];
 #pragma unroll
-            for (int mt = 0; mt < MT2; ++mt) {
+            for (int mt = 0; mt < MT1; ++mt) {
                 int r = 32 * mt + (ln & 31);
                 r = r < 2 * G::P1 ? r : 2 * G::P1 - 1;
                 const int bd = r >= G::P1 ? 1 : 0, p = r - bd * G::P1;
@@ -416,52 +483,57 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
                 tap = tap < 9 ? tap : 8;  // finite operand for the zero-weight column
                 const int toff = (tap / 3) * G::PW + tap % 3;
 #pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) acc[mt] = MFMA32(inp[pbase[mt] + toff], w1[s5], acc[mt]);
+                for (int mt = 0; mt < MT1; ++mt) acc[mt] = MFMA32(inp[pbase[mt] + toff], w1[s5], acc[mt]);
             }
-            store_relu_lds32<G::P1, G::PS, OFF1, MT2>(act, ln, acc);
+            const auto sink = to_lds(G::P1);
+#pragma unroll
+            for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = 32 * mt + 8 * (i / 4) + 4 * (ln >> 5) + (i % 4);
+                    const float v = acc[mt][i];
+                    if (r < 2 * G::P1) sink(r, ln & 31, v > 0.0f ? v : 0.0f);
+                }
         }
         LDS_FENCE();
         {  // conv2 32->32, pad 1
-            f32x16 acc[MT2];
-            conv32<G::P1, CW, CH, CW, G::PS, OFF1, 1, MT2>(act, tp.wp[0], bv2, w0, ln, acc);
-            LOAD_W0(tp.wp[1])
+            f32x16 acc[PL2::MTA];
+            f32x4 acc16[2];
+            conv32<G::P1, CW, CH, CW, G::PS, OFF1, 1>(act, tp.wp[0], tp.wf[0], bv2, bq2, w0, w16, ln, acc, acc16);
+            LOAD_W0(1)
+            LOAD_W16(1, PL3)
             LDS_FENCE();
-            store_relu_lds32<G::P1, G::PS, OFF1, MT2>(act, ln, acc);
+            conv_epilogue<G::P1>(ln, acc, acc16, to_lds(G::P1));
         }
         LDS_FENCE();
         {  // conv3 32->32, valid
-            f32x16 acc[MT3];
-            conv32<G::P3, G::W3, G::H3, CW, G::PS, OFF1, 0, MT3>(act, tp.wp[1], bv3, w0, ln, acc);
-            LOAD_W0(tp.wp[2])
+            f32x16 acc[PL3::MTA];
+            f32x4 acc16[2];
+            conv32<G::P3, G::W3, G::H3, CW, G::PS, OFF1, 0>(act, tp.wp[1], tp.wf[1], bv3, bq3, w0, w16, ln, acc, acc16);
+            LOAD_W0(2)
+            LOAD_W16(2, PL4)
             LDS_FENCE();
-            store_relu_lds32<G::P3, G::PS, OFF1, MT3>(act, ln, acc);
+            conv_epilogue<G::P3>(ln, acc, acc16, to_lds(G::P3));
         }
         LDS_FENCE();
         {  // conv4 32->32, valid -> flattened NCHW features
-            f32x16 acc[MT4];
-            conv32<G::P4, G::W4, G::H4, G::W3, G::PS, OFF1, 0, MT4>(act, tp.wp[2], bv4, w0, ln, acc);
-            LOAD_W0(tp.wp[0])
-            const int oc = ln & 31, h = ln >> 5;
-#pragma unroll
-            for (int mt = 0; mt < MT4; ++mt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int r = 32 * mt + 8 * (i / 4) + 4 * h + (i % 4);
-                    const int bd = r >= G::P4 ? 1 : 0, p = r - bd * G::P4;
-                    const float v = acc[mt][i];
-                    if (r < 2 * G::P4 && (bd == 0 || two)) feat[(size_t)(b0 + bd) * (NCH * G::P4) + oc * G::P4 + p] = v > 0.0f ? v : 0.0f;
-                }
+            f32x16 acc[PL4::MTA];
+            f32x4 acc16[2];
+            conv32<G::P4, G::W4, G::H4, G::W3, G::PS, OFF1, 0>(act, tp.wp[2], tp.wf[2], bv4, bq4, w0, w16, ln, acc, acc16);
+            LOAD_W0(0)
+            LOAD_W16(0, PL2)
+            conv_epilogue<G::P4>(ln, acc, acc16, [=](int r, int oc, float v) {
+                const int bd = r >= G::P4 ? 1 : 0;
+                if (bd == 0 || two) feat[(size_t)(b0 + bd) * (NCH * G::P4) + oc * G::P4 + (r - bd * G::P4)] = v;
+            });
         }
-#ifdef AZ_PROBE
-        for (int i = 0; i < 8; ++i) tacc[i] += ts[i + 1] - ts[i];
-        if (lane == 0 && blockIdx.x < 256 && progress / 4 <= 4) az_probe_buf[((size_t)blockIdx.x * 8 + wave) * 4 + (progress - 1) / 4] = __builtin_amdgcn_s_memrealtime() - rt0;
-#endif
         pair = nxt;
         if (pair >= pairs) break;
     }
 #undef NEXT_TICKET
 #undef LOAD_INPUT
 #undef LOAD_W0
+#undef LOAD_W16
 }
 
 // C[M][N] = act(A[M][K] * Bw[K][N] + bias[N]);  K % 32 == 0, N % BN == 0.
