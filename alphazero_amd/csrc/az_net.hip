@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
 // tile t is computed (two register staging sets); fragment reads run one k-step ahead of the MFMAs.
 
 template <int BM, int BN, int WM, int WN, bool RELU, int KT>
-__global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, const float *__restrict__ Bw,
+__global__ __launch_bounds__(256, 2) void k_gemm(const float *__restrict__ A, const float *__restrict__ Bw,
                                               const float *__restrict__ bias, float *__restrict__ C, int M, int N, int K,
                                               const int *__restrict__ dyn_count) {
     if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
@@ -1184,6 +1184,12 @@ static int launch_gemm(const float *A, const float *Bw, const float *bias, float
     // pick the largest tile that still gives every CU two resident blocks (512 blocks on 256 CUs):
     // a block's barrier and LDS-fill phases then overlap the other block's MFMAs
     const long long mb128 = (M + 127) / 128, mb64 = (M + 63) / 64;
+    static int force = -1;
+    if (force < 0) { const char *e = getenv("AZ_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    if (force == 1 && N % 128 == 0) return gemm_go<128, 128, 64, 64>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+    if (force == 2 && N % 64 == 0) return gemm_go<128, 64, 32, 64>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+    if (force == 3 && N % 64 == 0) return gemm_go<64, 64, 32, 32>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+    if (force == 4 && N % 128 == 0) return gemm_go<64, 128, 32, 64>(A, Bw, bias, C, M, N, K, relu, dyn, st);
     if (N % 128 == 0 && mb128 * (N / 128) >= 512) return gemm_go<128, 128, 64, 64>(A, Bw, bias, C, M, N, K, relu, dyn, st);
     if (N % 64 == 0 && mb128 * (N / 64) >= 512) return gemm_go<128, 64, 32, 64>(A, Bw, bias, C, M, N, K, relu, dyn, st);
     if (N % 64 == 0 && mb64 * (N / 64) >= 512) return gemm_go<64, 64, 32, 32>(A, Bw, bias, C, M, N, K, relu, dyn, st);

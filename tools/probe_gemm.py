@@ -11,12 +11,12 @@ import torch
 from alphazero_amd import _lib
 from alphazero_amd.games.othello import OthelloNet
 
-B = 4096
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 torch.manual_seed(0)
 net = OthelloNet(n=8).eval().to_hip(max_batch=B)
 L = _lib.lib()
 L.az_debug_read_probe.argtypes = [C.c_void_p, C.c_int]
-for stage, nblk in ((1, 512), (2, 512)):
+for stage, nblk in ((1, min(8192, (B // 128) * 8 if B >= 16384 else 512)), (2, min(8192, (B // 128) * 4 if B >= 16384 else 512))):
     print("stage", stage, "time us", net.time_stage(stage, B, 10) * 1e3)
     buf = np.zeros(nblk * 8, dtype=np.uint64)
     assert L.az_debug_read_probe(buf.ctypes.data, buf.size) == 0
