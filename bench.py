@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is `--waves` (1) self-play wave(s): every rank keeps `--games` (16384) Othello 8x8 games resident and
+A "step" is `--waves` (1) self-play wave(s): every rank keeps `--games` (32768) Othello 8x8 games resident and
 plays waves x games of them from the start position to the end at 100 MCTS simulations per move through the
 HIP engine (finished slots are refilled at once)
 (random-init OthelloNet(n=8) under torch.manual_seed(0), Dirichlet noise 0.03/0.25, tau linear(4,4),
@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=16384, help="concurrent games (engine slots) per GPU")
+    ap.add_argument("--games", type=int, default=32768, help="concurrent games (engine slots) per GPU")
     ap.add_argument("--waves", type=int, default=1, help="games per step per GPU = waves x games; finished slots are refilled, "
                                                            "so the ragged end of a wave (games last 60-65 plies) overlaps the next")
     ap.add_argument("--sims", type=int, default=100)
