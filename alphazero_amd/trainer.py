@@ -72,6 +72,8 @@ class AlphaZeroTrainer:
         self.device_memory = None   # originals + symmetry twins as CUDA tensors: what optimize_network trains on
         # list[Sample] like the reference's trainer.memory; switch off for large runs (millions of Python objects)
         self.materialize_memory = materialize_memory
+        # replay the SGD step as a captured HIP graph when the samples are device-resident (launch-bound otherwise)
+        self.graph_sgd = True
 
     def __str__(self):
         return f"{type(self).__name__}{self.game.capitalize()}" if self.game is not None else type(self).__name__
@@ -175,22 +177,79 @@ class AlphaZeroTrainer:
         sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
         self.loss_values[iter_idx] = {}
         bs = self.config.batch_size
+        graphed = (self.graph_sgd and self.device_memory is not None and torch.cuda.is_available()
+                   and torch.device(self.config.device).type == "cuda")
         for epoch in range(self.config.epochs):
             n_batches = self._n_samples() // bs
             if n_batches == 0:
                 raise ValueError(f"Too few samples in the memory ({self._n_samples()}) to create a batch with batch_size = {bs}")
-            pi_losses, v_losses = [], []
-            for x, pi, z in self._batch_generator(n_batches):
-                opt.zero_grad()
-                log_p, v = self.nn_twin(x)
-                loss_pi = -torch.sum(pi * log_p) / bs
-                loss_v = torch.sum((v - z) ** 2) / bs
-                (loss_pi + loss_v).backward()
-                opt.step()
-                pi_losses.append(loss_pi.cpu().item())
-                v_losses.append(loss_v.cpu().item())
+            if graphed:
+                pi_losses, v_losses = self._epoch_graphed(opt, n_batches, first=(epoch == 0))
+            else:
+                pi_losses, v_losses = [], []
+                for x, pi, z in self._batch_generator(n_batches):
+                    loss_pi, loss_v = self._sgd_step(opt, x, pi, z)
+                    pi_losses.append(loss_pi.cpu().item())
+                    v_losses.append(loss_v.cpu().item())
             self.loss_values[iter_idx][epoch] = {"pi": pi_losses, "v": v_losses}
             sched.step()
+
+    def _sgd_step(self, opt, x, pi, z):
+        """one optimisation step of the reference's loop (trainer.py:346-366)"""
+        bs = self.config.batch_size
+        opt.zero_grad(set_to_none=True)
+        log_p, v = self.nn_twin(x)
+        loss_pi = -torch.sum(pi * log_p) / bs
+        loss_v = torch.sum((v - z) ** 2) / bs
+        (loss_pi + loss_v).backward()
+        opt.step()
+        return loss_pi.detach(), loss_v.detach()
+
+    def _epoch_graphed(self, opt, n_batches, first):
+        """One epoch with the step (batch gather from the device memory, forward, backward, SGD update) captured once
+        as a HIP graph and replayed: the eager loop is bound by ~100 kernel launches and two host syncs per step.
+        The learning rate is a host scalar inside the captured optimizer kernels, so the graph is re-captured every
+        epoch (ExponentialLR, trainer.py:334).  Same arithmetic as _sgd_step; losses are read back once per epoch."""
+        m, bs, dev = self.device_memory, self.config.batch_size, torch.device(self.config.device)
+        perm = torch.randperm(m["z"].shape[0], device=m["z"].device)[: n_batches * bs].view(n_batches, bs)
+        step_t = torch.zeros(1, dtype=torch.long, device=dev)
+        pi_log = torch.zeros(n_batches, device=dev)
+        v_log = torch.zeros(n_batches, device=dev)
+
+        def batch_of(rows):
+            return (m["state"].index_select(0, rows).to(dev, torch.float32), m["pi"].index_select(0, rows).to(dev, torch.float32),
+                    m["z"].index_select(0, rows).to(dev, torch.float32).unsqueeze(1))
+
+        done = 0
+        if first:  # eager steps first: momentum buffers and MIOpen's algorithm choices must exist before the capture
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(min(3, n_batches)):
+                    lp, lv = self._sgd_step(opt, *batch_of(perm[done]))
+                    pi_log[done], v_log[done] = lp, lv
+                    done += 1
+            torch.cuda.current_stream().wait_stream(side)
+        if done < n_batches:
+            step_t.fill_(done)
+            opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                rows = perm.index_select(0, step_t).view(-1)
+                lp, lv = self._sgd_step(opt, *batch_of(rows))
+                pi_log.index_copy_(0, step_t, lp.view(1))
+                v_log.index_copy_(0, step_t, lv.view(1))
+                step_t += 1
+            # the capture itself did not execute anything: replay once per remaining batch
+            if os.environ.get("AZ_DEBUG_SGD"):
+                import time
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n_batches - done):
+                graph.replay()
+            if os.environ.get("AZ_DEBUG_SGD"):
+                torch.cuda.synchronize()
+                print(f"[sgd] {n_batches - done} graph replays: {(time.perf_counter() - t0) / (n_batches - done) * 1e3:.3f} ms each")
+        return pi_log.cpu().tolist(), v_log.cpu().tolist()
 
     def update_network(self, iter_idx):
         self.nn = self.nn_twin.clone()

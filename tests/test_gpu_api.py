@@ -234,3 +234,38 @@ def test_batched_arena_rollout_mcts():
     torch.manual_seed(0)
     st = BatchedArena("tictactoe", TicTacToeNet().eval(), opponent="mcts", n_sim=25, opponent_n_sim=100, seed=5).play_games(64)
     assert len(st["player1"]) + len(st["player2"]) + st["draw"] == 64
+
+
+def test_graphed_sgd_equals_eager_sgd(tmp_path, monkeypatch):
+    """optimize_network on the GPU: the epoch replayed as a captured HIP graph does the arithmetic of the eager loop
+    (same batches, same order; dropout switched off here because the two paths draw its mask from different streams)"""
+    from alphazero_amd.games import _convnet
+    monkeypatch.setattr(_convnet.ConvPolicyValueNet, "dropout", 0.0)
+    base.DEFAULT_MODELS_PATH = str(tmp_path) + "/"
+    tr = AlphaZeroTrainer(verbose=False, engine_slots=64, seed=2, materialize_memory=False)
+    tr.game = "othello"
+    tr.config = OthelloConfig(board_size=6, simulations=10, episodes=64, epochs=1, batch_size=128, iterations=1,
+                              do_eval=False, data_augmentation=True, device="cuda", learning_rate=0.001)  # one epoch: the capture perturbs the
+    # generator state that the next epoch's permutation would be drawn from
+    torch.manual_seed(3)
+    tr.setup()
+    tr.self_play(0)
+    out = {}
+    for mode in (False, True):
+        tr.graph_sgd = mode
+        torch.manual_seed(11)
+        tr.optimize_network(0)
+        out[mode] = ({k: v.detach().clone() for k, v in tr.nn_twin.state_dict().items()}, tr.loss_values[0])
+    n_steps = tr.device_memory["z"].shape[0] // 128
+    assert n_steps > 8 and len(out[True][1][0]["pi"]) == n_steps and len(out[True][1][0]["v"]) == n_steps
+    # the two paths run the same steps on the same batches; MIOpen's f32 reductions are not order-stable, and SGD
+    # amplifies the last-bit differences step by step: tight on the first steps, statistical afterwards
+    for k in ("pi", "v"):
+        g, e = np.array(out[True][1][0][k]), np.array(out[False][1][0][k])
+        assert np.allclose(g[:6], e[:6], rtol=1e-3, atol=1e-5), (k, g[:6], e[:6])
+        assert abs(g.mean() - e.mean()) < 0.01 * abs(e.mean()) + 1e-3, (k, g.mean(), e.mean())
+    for k in ("fc1.weight", "conv2.weight", "fc_probs.weight"):
+        a_, b_ = out[True][0][k].float().flatten(), out[False][0][k].float().flatten()
+        cos = float(torch.dot(a_, b_) / (a_.norm() * b_.norm()))
+        assert cos > 0.98, (k, cos)  # ~130 momentum-SGD steps amplify the last-bit differences of the f32 reductions
+    assert not torch.equal(out[True][0]["fc1.weight"], tr.nn.state_dict()["fc1.weight"].to("cuda"))
