@@ -136,3 +136,75 @@ def test_rollout_mode_equals_oracle(tag, n_games, n_sim, slots):
     assert eng.stats()["games_done"] == n_games and len(got["z"]) == len(ref["z"])
     for k in ("state", "z", "meta", "visits", "pi"):
         assert np.array_equal(got[k], ref[k]), k
+
+
+def _replay_check(gid, H, W, smp, n_games, n_sim, tmax):
+    """size-independent properties of a self-play run, checked for every sample against the CPU rules oracle:
+    consecutive states of a game are linked by its recorded action (legal, oracle play), the first state is the start
+    position, z is the final winner seen from the side to move, pi is the visit distribution (tau = 1) or the one-hot
+    of a most-visited move (tau = 0), and every search ran exactly n_sim simulations on top of the reused subtree"""
+    st, pi, z, meta, vis = (smp[k] for k in ("state", "pi", "z", "meta", "visits"))
+    assert len(np.unique(meta[:, 0])) == n_games
+    first = np.flatnonzero(meta[:, 1] == 0)
+    last = np.r_[first[1:], len(z)] - 1
+    assert np.array_equal(meta[first, 0], np.unique(meta[:, 0]))
+    assert np.array_equal(meta[:, 1], np.arange(len(z)) - np.repeat(first, last - first + 1))  # move_idx 0, 1, 2, ...
+    player = meta[:, 2].astype(np.int8)
+    grids = (st.reshape(len(z), -1) * player[:, None]).astype(np.int8)  # undo the normalisation
+    b0 = O.new_board(gid, H, W)
+    start = np.array([b0.grid[i] for i in range(H * W)], np.int8) if hasattr(b0, "grid") else None
+    if start is not None:
+        assert (grids[first] == start[None]).all() and (player[first] == 1).all()
+    legal = O.batch_legal(gid, H, W, grids, player)
+    assert legal[np.arange(len(z)), meta[:, 3]].all()  # every recorded action was legal
+    ng, npl, status = O.batch_play(gid, H, W, grids, player, meta[:, 3])
+    assert (status == 0).all()
+    inner = np.ones(len(z), bool)
+    inner[last] = False
+    nxt = np.flatnonzero(inner) + 1
+    assert np.array_equal(ng[inner], grids[nxt]) and np.array_equal(npl[inner], player[nxt])
+    over, win, _ = O.batch_status(gid, H, W, ng[last], npl[last])
+    assert over.all()  # the game ends exactly after its last sample
+    assert np.array_equal(z, np.repeat(win, last - first + 1) * player)
+    over_mid, _, _ = O.batch_status(gid, H, W, grids, player)
+    assert not over_mid.any()
+    # visit statistics
+    assert (vis[~legal.astype(bool)] == 0).all()
+    tot = vis.sum(1)
+    assert (tot[first] == n_sim).all() and (tot >= n_sim).all()  # every simulation descends into one root child; reuse adds more
+    tau1 = meta[:, 1] <= tmax
+    assert np.allclose(pi[tau1], vis[tau1] / tot[tau1, None], atol=1e-6)
+    arg = pi[~tau1].argmax(1)
+    assert np.allclose(pi[~tau1].sum(1), 1) and (pi[~tau1].max(1) == 1).all()
+    assert (vis[~tau1][np.arange(len(arg)), arg] == vis[~tau1].max(1)).all()
+    assert (pi[~tau1].argmax(1) == meta[~tau1, 3]).all()  # tau = 0 plays the move it reports
+
+
+def test_full_size_othello_selfplay_properties():
+    """BASELINE config 2 at full size (4096 concurrent Othello 8x8 games, 100 simulations per move, real network)"""
+    from alphazero_amd.games.othello import OthelloNet
+    import torch
+    torch.manual_seed(0)
+    G, n_sim = 4096, 100
+    eng = E.SelfPlayEngine(0, 8, 8, n_slots=G, n_sim=n_sim, net=OthelloNet(n=8).eval().to_hip(max_batch=G), seed=0)
+    smp = sort_samples(eng.run(G))
+    stt = eng.stats()
+    assert stt["games_done"] == G and stt["samples"] == len(smp["z"])
+    plies = len(smp["z"]) / G
+    assert 58.5 < plies < 62.0, plies  # reference: 60.3 plies per game (SURVEY 8d, config 2)
+    assert 0.85 < stt["net_evals"] / (len(smp["z"]) * n_sim) <= 1.0  # ~0.92 evaluations per simulation
+    _replay_check(0, 8, 8, smp, G, n_sim, tmax=4)
+
+
+def test_full_size_connect4_selfplay_properties():
+    """BASELINE config 4 at full size (8192 concurrent Connect4 6x7 games, 200 simulations per move)"""
+    from alphazero_amd.games.connect4 import Connect4Net
+    import torch
+    torch.manual_seed(0)
+    G, n_sim = 8192, 200
+    eng = E.SelfPlayEngine(1, 6, 7, n_slots=G, n_sim=n_sim, net=Connect4Net(7, 6).eval().to_hip(max_batch=G), seed=0)
+    smp = sort_samples(eng.run(G))
+    assert eng.stats()["games_done"] == G
+    plies = len(smp["z"]) / G
+    assert 24 < plies < 31, plies  # reference: 27 plies per game (SURVEY 8d, config 4)
+    _replay_check(1, 6, 7, smp, G, n_sim, tmax=4)
