@@ -901,7 +901,16 @@ struct az_net {
     float *feat, *h1, *h2;
     MlpParams mlp;
     bool committed;
+    // live per-stage timing (az_net_profile): HIP events around every stage launch, harvested in batches
+    bool prof = false;
+    int last_trunk_two_boards = 0;
+    std::vector<hipEvent_t> prof_ev;  // [PROF_SLOTS][5]
+    std::vector<int> prof_kind;       // trunk kernel used by the forward in that slot
+    int prof_used = 0;
+    double prof_ms[5] = {0, 0, 0, 0, 0};  // k_trunk2, fc1, fc2, heads, k_trunk (one board per wave)
+    long long prof_n[5] = {0, 0, 0, 0, 0};
 };
+#define PROF_SLOTS 2048
 
 #define AZ_TRY(x) do { int _rc = (x); if (_rc != AZ_OK) return _rc; } while (0)
 
@@ -947,6 +956,7 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
 extern "C" void az_net_destroy(az_net *n) {
     if (!n) return;
     for (void *p : n->allocs) (void)hipFree(p);
+    for (auto &e : n->prof_ev) (void)hipEventDestroy(e);
     delete n;
 }
 
@@ -1133,7 +1143,8 @@ template <int CH, int CW>
 static int launch_trunk(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
     // two boards per wave on 32x32x2 pays from ~4096 boards up (16384: 325 vs 331 us); below that the one-board-
     // per-wave kernel fills the chip better (2048: 45 vs 77 us).  AZ_TRUNK_V1=1 forces the latter.
-    if (!trunk_v1() && B >= 4096) return launch_trunk2<CH, CW>(n, in, B, dyn, st);
+    n->last_trunk_two_boards = (!trunk_v1() && B >= 4096) ? 1 : 0;
+    if (n->last_trunk_two_boards) return launch_trunk2<CH, CW>(n, in, B, dyn, st);
     using G = TrunkGeom<CH, CW>;
     static bool attr_set = false;
     static int lds_bytes = G::LDS_BYTES;
@@ -1233,6 +1244,43 @@ static int run_stage(az_net *n, int stage, const float *d_input, int B, const in
     }
 }
 
+static int prof_harvest(az_net *n) {
+    if (n->prof_used == 0) return AZ_OK;
+    AZ_HIP(hipEventSynchronize(n->prof_ev[(size_t)(n->prof_used - 1) * 5 + 4]));
+    for (int i = 0; i < n->prof_used; ++i)
+        for (int s = 0; s < 4; ++s) {
+            float ms = 0.0f;
+            AZ_HIP(hipEventElapsedTime(&ms, n->prof_ev[(size_t)i * 5 + s], n->prof_ev[(size_t)i * 5 + s + 1]));
+            const int slot = (s == 0 && !n->prof_kind[i]) ? 4 : s;
+            n->prof_ms[slot] += ms;
+            n->prof_n[slot] += 1;
+        }
+    n->prof_used = 0;
+    return AZ_OK;
+}
+
+// az_net_profile(net, 1): every forward from now on brackets its four stage launches with HIP events on the
+// forward's stream; az_net_profile_read harvests them: total ms and launch count of k_trunk2, k_gemm fc1, k_gemm fc2,
+// k_heads and (index 4) the one-board-per-wave k_trunk.  The events cost ~1 us per launch on the host side.
+extern "C" int az_net_profile(az_net *n, int enable) {
+    AZ_REQUIRE(n, AZ_EINVAL, "null net");
+    if (enable && n->prof_ev.empty()) {
+        n->prof_ev.resize((size_t)PROF_SLOTS * 5);
+        n->prof_kind.assign(PROF_SLOTS, 0);
+        for (auto &e : n->prof_ev) AZ_HIP(hipEventCreate(&e));
+    }
+    if (enable) { n->prof_used = 0; for (int i = 0; i < 5; ++i) { n->prof_ms[i] = 0; n->prof_n[i] = 0; } }
+    n->prof = enable != 0;
+    return AZ_OK;
+}
+
+extern "C" int az_net_profile_read(az_net *n, double *ms_total, int64_t *launches) {
+    AZ_REQUIRE(n && ms_total && launches, AZ_EINVAL, "null argument");
+    AZ_TRY(prof_harvest(n));
+    for (int i = 0; i < 5; ++i) { ms_total[i] = n->prof_ms[i]; launches[i] = n->prof_n[i]; }
+    return AZ_OK;
+}
+
 static int forward_impl(az_net *n, const float *d_input, int B, const int *dyn, float *d_probs, float *d_value, void *stream) {
     AZ_REQUIRE(n && d_input && d_probs && d_value, AZ_EINVAL, "null argument");
     AZ_REQUIRE(n->committed, AZ_ESTATE, "az_net_commit has not been called since the last az_net_set_tensor");
@@ -1242,7 +1290,18 @@ static int forward_impl(az_net *n, const float *d_input, int B, const int *dyn, 
         hipLaunchKernelGGL(k_mlp, dim3((B + 63) / 64), dim3(64), 0, st, d_input, B, dyn, n->mlp, d_probs, d_value);
         return AZ_OK;
     }
-    for (int s = 0; s < 4; ++s) AZ_TRY(run_stage(n, s, d_input, B, dyn, d_probs, d_value, st));
+    if (!n->prof) {
+        for (int s = 0; s < 4; ++s) AZ_TRY(run_stage(n, s, d_input, B, dyn, d_probs, d_value, st));
+        return AZ_OK;
+    }
+    if (n->prof_used == PROF_SLOTS) AZ_TRY(prof_harvest(n));
+    hipEvent_t *ev = n->prof_ev.data() + (size_t)n->prof_used * 5;
+    AZ_HIP(hipEventRecord(ev[0], st));
+    for (int s = 0; s < 4; ++s) {
+        AZ_TRY(run_stage(n, s, d_input, B, dyn, d_probs, d_value, st));
+        AZ_HIP(hipEventRecord(ev[s + 1], st));
+    }
+    n->prof_kind[n->prof_used++] = n->last_trunk_two_boards;
     return AZ_OK;
 }
 

@@ -138,6 +138,17 @@ class HipNet:
         check(lib().az_net_time_stage(self.h, stage, B, iters, _stream_ptr(), C.byref(ms)))
         return float(ms.value)
 
+    def profile(self, enable=True):
+        """bracket every stage launch of the following forwards with HIP events (az_net_profile)"""
+        check(lib().az_net_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        """-> {kernel: (total ms, launches)} since profile(True)"""
+        ms, n = (C.c_double * 5)(), (C.c_int64 * 5)()
+        check(lib().az_net_profile_read(self.h, ms, n))
+        names = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads", "k_trunk"]
+        return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+
     def close(self):
         if getattr(self, "h", None):
             lib().az_net_destroy(self.h)

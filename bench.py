@@ -24,7 +24,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
-STAGE_NAMES = ["k_trunk (conv1-4)", "k_gemm fc1", "k_gemm fc2", "k_heads"]
+STAGE_NAMES = ["k_trunk2 (conv1-4)", "k_gemm fc1", "k_gemm fc2", "k_heads"]
 
 
 def stage_flops(n):
@@ -33,7 +33,7 @@ def stage_flops(n):
     return [conv, 2 * fin * 1024, 2 * 1024 * 512, 2 * 512 * (n * n + 2)]
 
 
-def cpu_baseline(state_dict, n_games=3, n_sim=100):
+def cpu_baseline(state_dict, n_games=6, n_sim=100):
     """the CPU oracle (C port of the reference's self-play loop) on one host core, same weights/config"""
     from oracle import oracle as O
     net = O.ConvNet(O.OTHELLO, 8, 8, {k: v.cpu().numpy() for k, v in state_dict.items() if not k.endswith("num_batches_tracked")})
@@ -102,13 +102,17 @@ def main():
 
     for w in range(args.warmup):
         step(w)
+    if rank == 0:
+        hnet.profile(True)  # HIP events around every network kernel launch of the timed region (engine's stream)
     sync()
     t0 = time.perf_counter()
-    n_samples_total = 0
+    n_samples_total, evals_total = 0, 0
     for k in range(args.steps):
         n_samples_total += step(args.warmup + k)
+        evals_total += eng.stats()["net_evals"]
     sync()
     dt = time.perf_counter() - t0
+    prof = hnet.profile_read() if rank == 0 else None
     t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -130,20 +134,34 @@ def main():
             "plies_per_game": samples / games, "net_evals_last_step": st["net_evals"], "lockstep_iters_last_step": st["lockstep_iters"],
             "max_tree_nodes_per_game": st["max_nodes_used"],
         }
-        # roofline of the dominant kernel: per-launch time measured here with HIP events on the engine's stream
+        # roofline of the dominant kernel, measured live over the timed region: algorithmic FLOPs of the boards the
+        # network evaluated there / the time its launches took (HIP events on the engine's stream, az_net_profile)
         fl = stage_flops(n)
-        ms = [hnet.time_stage(s, G, iters=30) for s in range(4)]
-        dom = int(np.argmax(ms))
-        ach = fl[dom] * G / (ms[dom] * 1e-3) / 1e12
+        names = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads"]
+        tot_ms = [prof[k][0] for k in names]
+        tot_ms[0] += prof["k_trunk"][0]  # the few small-batch launches of the one-board-per-wave trunk kernel
+        dom = int(np.argmax(tot_ms))
+        ach = fl[dom] * evals_total / (tot_ms[dom] * 1e-3) / 1e12
+        kname = names[dom]
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per full-batch launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         if os.path.exists(tfile) and json.load(open(tfile)).get("batch") == G:
             traffic = json.load(open(tfile)).get(["k_trunk", "k_gemm_fc1", "k_gemm_fc2", "k_heads"][dom])
-        out["roofline"] = {"bound": "mfma", "kernel": STAGE_NAMES[dom], "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+        full = [hnet.time_stage(s, G, iters=20) for s in range(4)]  # context: one launch at the full batch
+        out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "launch_ms": ms[dom], "algorithmic_flops_per_launch": fl[dom] * G,
-                           "all_stages_ms": dict(zip(STAGE_NAMES, ms)),
-                           "forward_tflops": sum(fl) * G / (sum(ms) * 1e-3) / 1e12}
+                           "launches": prof[kname][1], "avg_launch_ms": prof[kname][0] / max(1, prof[kname][1]),
+                           "avg_boards_per_launch": evals_total / max(1, prof[kname][1] + (prof["k_trunk"][1] if dom == 0 else 0)),
+                           "algorithmic_flops_per_board": fl[dom], "boards_evaluated": evals_total,
+                           "timed_region_ms": {k: prof[k][0] for k in prof}, "timed_region_launches": {k: prof[k][1] for k in prof},
+                           "full_batch_launch_ms": dict(zip(STAGE_NAMES, full)),
+                           "full_batch_tflops": {STAGE_NAMES[i]: fl[i] * G / (full[i] * 1e-3) / 1e12 for i in range(4)},
+                           "forward_tflops": sum(fl) * evals_total / (sum(tot_ms) * 1e-3) / 1e12}
+        # the tree kernels' side of SURVEY 8d: algorithmic HBM bytes of select / expand / backup per simulation
+        sims_per_gpu = samples * args.sims / dt / world
+        out["tree_hbm"] = {"algorithmic_bytes_per_sim": 919, "achieved": sims_per_gpu * 919 / 1e9, "peak": 8000.0, "unit": "GB/s",
+                           "frac": sims_per_gpu * 919 / 8e12,
+                           "note": "per GPU; k_step takes 4-5 % of a step, the path is bound by the network's MFMA work"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model.state_dict())
         print(json.dumps(out), flush=True)

@@ -92,6 +92,11 @@ int64_t az_net_flops_per_board(const az_net *net);
 /* times `iters` back-to-back launches of one forward stage with HIP events on `stream`;
  * stage: 0 conv trunk, 1 fc1, 2 fc2, 3 heads, -1 whole forward.  *ms_per_launch out. */
 int az_net_time_stage(az_net *net, int stage, int B, int iters, void *stream, float *ms_per_launch);
+/* Live measurement (the idiom of timers.py:53-76 applied per kernel): while enabled, every forward brackets its stage
+ * launches with HIP events on its own stream.  ms_total[5] / launches[5]: k_trunk2, k_gemm fc1, k_gemm fc2, k_heads,
+ * k_trunk (one board per wave, small batches). */
+int az_net_profile(az_net *net, int enable);
+int az_net_profile_read(az_net *net, double *ms_total, int64_t *launches);
 
 /* ---- self-play engine (K3/K4/K7/K8/K9) -------------------------------------------------------
  * replaces AlphaZeroTrainer.self_play (trainer.py:215-273) driving AlphaZeroPlayer.get_move

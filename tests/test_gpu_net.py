@@ -88,3 +88,24 @@ def test_large_batch_kernel_equals_small_batch_kernel(tag):
         idx = (idx * 7 + 3) % n0  # not the same neighbour pairs in every pass
         p, v = hnet.forward(canon[idx].contiguous())
         assert torch.equal(p, p_ref[idx]) and torch.equal(v, v_ref[idx]), (tag, B)
+
+
+def test_live_stage_profile():
+    """az_net_profile: HIP events around every stage launch; the counts tell which trunk kernel served which batch"""
+    game, gid, H, W, A, n = TAGS["othello8"]
+    fx, sd, onet, _ = nets("othello8")
+    hnet = E.HipNet(gid, H, W, sd, max_batch=5000)
+    x = torch.zeros((5000, 64), device="cuda")
+    p0, v0 = hnet.forward(x)
+    hnet.profile(True)
+    for _ in range(3):
+        p1, v1 = hnet.forward(x)
+    for _ in range(2):
+        hnet.forward(x[:100].contiguous())
+    prof = hnet.profile_read()
+    assert prof["k_trunk2"][1] == 3 and prof["k_trunk"][1] == 2 and prof["k_gemm fc1"][1] == 5 and prof["k_heads"][1] == 5
+    assert all(prof[k][0] > 0 for k in prof) and prof["k_trunk2"][0] / 3 > prof["k_trunk"][0] / 2
+    hnet.profile(False)
+    hnet.forward(x)
+    assert hnet.profile_read()["k_heads"][1] == 5  # nothing recorded while switched off
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
