@@ -3,7 +3,7 @@
 // Replaces OthelloNet / Connect4Net / TicTacToeNet .forward in eval mode (othello.py:341-382,
 // connect4.py:370-412, tictactoe.py:289-316) + PolicyValueNetwork.predict (base.py:350-355).
 //
-// All matrix work runs on the f32-input matrix cores (v_mfma_f32_16x16x4_f32): exact f32
+// All matrix work runs on the f32-input matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32): exact f32
 // products and a k-ordered f32 accumulation chain, i.e. the reference's arithmetic type (the
 // reference computes in torch float32), not a reduced-precision path.  Eval-mode BatchNorm is
 // folded into the preceding layer in float64 at upload (az_net_commit).
@@ -14,9 +14,10 @@
 //   heads: softmax as m = max, e = det_exp(l - m), S = sequential sum, p = e / S; v = det_tanh
 //
 // Kernels
-//   k_trunk<CH,CW> : conv1 (VALU) + conv2..4 (implicit GEMM on MFMA), one wavefront per board,
-//                    activations never leave the wave's private LDS region; weights stream from
-//                    L2 already tiled in MFMA B-fragment order (one coalesced dword per lane).
+//   k_trunk2<CH,CW>: conv1..4, two boards per wavefront on 32x32x2 MFMA, persistent 8-wave workgroups, activations
+//                    never leave the wave's private LDS region; weights stream from L2 already tiled in MFMA
+//                    B-fragment order (one coalesced dword per lane).  Batches from 4096 boards up.
+//   k_trunk<CH,CW> : the same layers, one wavefront per board on 16x16x4 MFMA: smaller batches.
 //   k_gemm<...>    : LDS-tiled f32 MFMA GEMM with bias(+ReLU) epilogue for fc1 / fc2.
 //   k_heads        : policy+value GEMM (N padded to 16) fused with softmax / tanh.
 //   k_mlp          : the 316-parameter TicTacToe MLP, one thread per board.

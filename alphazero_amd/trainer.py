@@ -241,14 +241,8 @@ class AlphaZeroTrainer:
                 v_log.index_copy_(0, step_t, lv.view(1))
                 step_t += 1
             # the capture itself did not execute anything: replay once per remaining batch
-            if os.environ.get("AZ_DEBUG_SGD"):
-                import time
-                torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(n_batches - done):
                 graph.replay()
-            if os.environ.get("AZ_DEBUG_SGD"):
-                torch.cuda.synchronize()
-                print(f"[sgd] {n_batches - done} graph replays: {(time.perf_counter() - t0) / (n_batches - done) * 1e3:.3f} ms each")
         return pi_log.cpu().tolist(), v_log.cpu().tolist()
 
     def update_network(self, iter_idx):
