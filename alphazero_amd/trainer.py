@@ -119,6 +119,14 @@ class AlphaZeroTrainer:
                                           sample_capacity=c.episodes * plies)
         return self._engine
 
+    @staticmethod
+    def _dist():
+        """(rank, world) of the torch.distributed job this trainer runs in (one process per GPU), (0, 1) outside one"""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
     def self_play(self, iter_idx):
         """trainer.py:215-286: all episodes are played concurrently on the engine; samples (normalised) and their
         symmetry twins stay on the device in self.device_memory; self.memory mirrors them as Sample objects"""
@@ -126,7 +134,23 @@ class AlphaZeroTrainer:
         eng = self._ensure_engine()
         gid, H, W, A = self._shape()
         n = self.config.episodes
-        smp = eng.run(n, first_game_id=iter_idx * n)
+        rank, world = self._dist()
+        if world == 1:
+            smp = eng.run(n, first_game_id=iter_idx * n)
+        else:
+            # the episodes are sharded by game id (disjoint Philox streams, no collective while playing), then every
+            # rank receives all samples: the same memory a single process would have built
+            from .dist import all_gather_samples
+            per = (n + world - 1) // world
+            lo = min(n, rank * per)
+            cnt = min(per, n - lo)
+            if cnt > 0:
+                smp = eng.run(cnt, first_game_id=iter_idx * n + lo)
+            else:
+                smp = {"state": torch.zeros((0, H, W), dtype=torch.int8, device="cuda"), "pi": torch.zeros((0, A), device="cuda"),
+                       "z": torch.zeros(0, dtype=torch.int8, device="cuda"), "meta": torch.zeros((0, 4), dtype=torch.int32, device="cuda"),
+                       "visits": torch.zeros((0, A), dtype=torch.int32, device="cuda")}
+            smp = {k: v.cuda() for k, v in all_gather_samples(smp).items()}
         meta = smp["meta"]
         order = torch.argsort(meta[:, 0].long() * 4096 + meta[:, 1].long())  # (episode, move) order of the reference's loop
         smp = {k: v[order].contiguous() for k, v in smp.items()}
@@ -171,6 +195,23 @@ class AlphaZeroTrainer:
                    torch.tensor(z, dtype=torch.float32, device=dev))
 
     def optimize_network(self, iter_idx):
+        rank, world = self._dist()
+        if world > 1:
+            # the reference's optimisation is one sequential SGD run (trainer.py:320-381): rank 0 does it, the others
+            # wait for the weights (4.46 MB for OthelloNet 8x8)
+            from .dist import broadcast_state_dict
+            if rank == 0:
+                self._optimize_local(iter_idx)
+            else:
+                self.nn_twin = self.nn.clone()
+                self.loss_values[iter_idx] = {}
+            if next(self.nn_twin.parameters()).device.type != "cuda" and torch.distributed.get_backend() == "nccl":
+                raise ValueError("distributed training over RCCL needs config.device = 'cuda'")
+            broadcast_state_dict(self.nn_twin, src=0)
+            return
+        self._optimize_local(iter_idx)
+
+    def _optimize_local(self, iter_idx):
         self.nn_twin = self.nn.clone()
         self.nn_twin.train()
         opt = torch.optim.SGD(self.nn_twin.parameters(), lr=self.config.learning_rate, momentum=0.9, weight_decay=0.0001)
@@ -264,7 +305,7 @@ class AlphaZeroTrainer:
         self.eval_results = {"eval_opponent": opp, "eval_episodes": self.config.eval_episodes, "results": {}}
 
     def evaluate(self, iter_idx):
-        if not self.config.do_eval:
+        if not self.config.do_eval or self._dist()[0] != 0:  # in a multi-GPU job rank 0 evaluates and writes the files
             return
         eval_player = AlphaZeroPlayer(n_sim=self.config.simulations, compute_time=self.config.compute_time, nn=self.nn)
         if self.config.eval_opponent in ("random", "greedy", "mcts") and self.config.simulations is not None:
@@ -322,18 +363,21 @@ class AlphaZeroTrainer:
         c.push = c.push or c.push_checkpoints
         c.save = c.save or c.push or c.save_checkpoints
         self.setup()
-        self.save_player_config(experiment_name)
+        writer = self._dist()[0] == 0  # multi-GPU job: rank 0 owns the files
+        if writer:
+            self.save_player_config(experiment_name)
         for it in range(c.iterations):
             self.print(f"\n----- Iteration {it+1}/{c.iterations} -----")
             self.self_play(it)
             self.optimize_network(it)
             self.update_network(it)
             self.evaluate(it)
-            self.save_training_stats(experiment_name)
-            if c.save_checkpoints:
+            if writer:
+                self.save_training_stats(experiment_name)
+            if c.save_checkpoints and writer:
                 self.save_player_pt(f"{experiment_name}-chkpt-{it+1}",
                                     path=os.path.join(base.DEFAULT_MODELS_PATH, experiment_name, "checkpoints"))
-        if c.save:
+        if c.save and writer:
             self.save_player_pt(experiment_name)
 
     def setup(self):

@@ -269,3 +269,51 @@ def test_graphed_sgd_equals_eager_sgd(tmp_path, monkeypatch):
         cos = float(torch.dot(a_, b_) / (a_.norm() * b_.norm()))
         assert cos > 0.98, (k, cos)  # ~130 momentum-SGD steps amplify the last-bit differences of the f32 reductions
     assert not torch.equal(out[True][0]["fc1.weight"], tr.nn.state_dict()["fc1.weight"].to("cuda"))
+
+
+def _dist_trainer_worker(rank, world, port, tmp, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # gloo: both ranks share this box's single GPU
+    try:
+        base.DEFAULT_MODELS_PATH = tmp + "/"
+        tr = AlphaZeroTrainer(verbose=False, engine_slots=32, seed=6, materialize_memory=False)
+        tr.game = "othello"
+        tr.config = OthelloConfig(board_size=6, simulations=8, episodes=21, epochs=1, batch_size=64, iterations=1,
+                                  do_eval=True, eval_opponent="random", eval_episodes=4, data_augmentation=True, device="cpu")
+        torch.manual_seed(9)
+        tr.setup()
+        tr.self_play(0)
+        tr.optimize_network(0)
+        tr.update_network(0)
+        tr.evaluate(0)
+        out[rank] = {"n": int(tr.device_memory["z"].shape[0]), "state": tr.device_samples["state"].cpu(), "meta": tr.device_samples["meta"].cpu(),
+                     "pi": tr.device_samples["pi"].cpu(), "w": tr.nn.fc1.weight.detach().cpu().clone(),
+                     "evaluated": tr.eval_results is not None and 0 in tr.eval_results.get("results", {}), "losses": len(tr.loss_values[0])}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_equal_one_rank(tmp_path):
+    """one process per GPU (here: two gloo ranks on the one GPU of the box): the episodes are sharded by game id,
+    every rank ends with the memory a single process builds; rank 0 trains and evaluates, rank 1 receives the weights"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_dist_trainer_worker, args=(r, 2, 29577, str(tmp_path), out)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs) and len(out) == 2
+    a, b = out[0], out[1]
+    assert a["n"] == b["n"] and torch.equal(a["state"], b["state"]) and torch.equal(a["meta"], b["meta"]) and torch.equal(a["pi"], b["pi"])
+    assert torch.equal(a["w"], b["w"]) and a["evaluated"] and not b["evaluated"] and a["losses"] == 1 and b["losses"] == 0
+    # single process, same seed and episodes: the very same samples
+    base.DEFAULT_MODELS_PATH = str(tmp_path) + "/"
+    tr = AlphaZeroTrainer(verbose=False, engine_slots=32, seed=6, materialize_memory=False)
+    tr.game = "othello"
+    tr.config = OthelloConfig(board_size=6, simulations=8, episodes=21, epochs=1, batch_size=64, iterations=1, do_eval=False, device="cpu")
+    torch.manual_seed(9)
+    tr.setup()
+    tr.self_play(0)
+    assert torch.equal(tr.device_samples["state"].cpu(), a["state"]) and torch.equal(tr.device_samples["meta"].cpu(), a["meta"])
+    assert torch.equal(tr.device_samples["pi"].cpu(), a["pi"])
