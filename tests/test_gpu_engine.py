@@ -208,3 +208,21 @@ def test_full_size_connect4_selfplay_properties():
     plies = len(smp["z"]) / G
     assert 24 < plies < 31, plies  # reference: 27 plies per game
     _replay_check(1, 6, 7, smp, G, n_sim, tmax=4)
+
+
+def test_results_do_not_depend_on_the_batch_shape():
+    """the same game ids played 4096 at a time (two-board trunk kernel, 128-wide GEMM tiles, slot = game) and 384 at a
+    time (one-board trunk kernel, small tiles, slots refilled ~11 times) give the same samples bit for bit: a game's
+    trajectory depends on its id only (Philox keyed by game id; every network row depends on its board only)"""
+    from alphazero_amd.games.othello import OthelloNet
+    import torch
+    torch.manual_seed(0)
+    model = OthelloNet(n=8).eval()
+    G, n_sim = 4096, 30
+    big = E.SelfPlayEngine(0, 8, 8, n_slots=G, n_sim=n_sim, net=model.to_hip(max_batch=G), seed=3)
+    a = sort_samples(big.run(G, first_game_id=500))
+    small = E.SelfPlayEngine(0, 8, 8, n_slots=384, n_sim=n_sim, net=model.to_hip(max_batch=384), seed=3, sample_capacity=G * 70)
+    b = sort_samples(small.run(G, first_game_id=500))
+    assert len(a["z"]) == len(b["z"])
+    for k in ("state", "z", "meta", "visits", "pi"):
+        assert np.array_equal(a[k], b[k]), k
