@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
     }
     PSTAMP(6)
 #ifdef AZ_PROBE
-    if (BACKUP && SELECT && sim == 50 && (threadIdx.x & 63) == 0) {
+    if (BACKUP && SELECT && sim == 50 && (threadIdx.x & 63) == 0 && blockIdx.x < 1024) {  // az_step_probe holds 1024 blocks x 4 waves
         unsigned long long *o = az_step_probe + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
         for (int i = 0; i < 7; ++i) o[i] = pt[i];
         o[7] = (unsigned long long)depth;

@@ -11,7 +11,7 @@ import torch
 from alphazero_amd import _lib, engine as E
 from alphazero_amd.games.othello import OthelloNet
 
-G = 4096
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 torch.manual_seed(0)
 net = OthelloNet(n=8).eval().to_hip(max_batch=G)
 eng = E.SelfPlayEngine(0, 8, 8, n_slots=G, n_sim=100, net=net, seed=0, max_plies=128, sample_capacity=G * 72)
