@@ -1,0 +1,96 @@
+"""CPU, only where the Python reference is mounted (/root/reference: this container, never the GPU box): the host-side
+mirror classes played side by side with the reference's own classes, and the committed golden fixtures regenerated
+from the reference and compared with the files in tests/golden/ (they are the reference's outputs, not ours)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference/alphazero"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference not mounted")
+
+
+@pytest.fixture(scope="module")
+def R():
+    from tools import gen_golden
+    return gen_golden.load_reference()
+
+
+def _boards(R, tag):
+    from alphazero_amd.games.connect4 import Connect4Board
+    from alphazero_amd.games.othello import OthelloBoard
+    from alphazero_amd.games.tictactoe import TicTacToeBoard
+    if tag.startswith("othello"):
+        n = int(tag[-1])
+        return R.oth.OthelloBoard(n=n), OthelloBoard(n=n)
+    if tag == "connect4":
+        return R.c4.Connect4Board(width=7, height=6), Connect4Board(width=7, height=6)
+    return R.ttt.TicTacToeBoard(), TicTacToeBoard()
+
+
+@pytest.mark.parametrize("tag", ["othello8", "othello6", "connect4", "tictactoe"])
+def test_boards_side_by_side(R, tag):
+    rng = np.random.RandomState(7)
+    for game in range(12):
+        ref, mine = _boards(R, tag)
+        while True:
+            assert ref.is_game_over() == mine.is_game_over()
+            assert np.array_equal(np.asarray(ref.grid), np.asarray(mine.grid)) and ref.player == mine.player
+            assert ref.get_score() == mine.get_score()
+            if ref.is_game_over():
+                assert ref.get_winner() == mine.get_winner()
+                break
+            a, b = ref.get_moves(), mine.get_moves()
+            key = (lambda m: int(m)) if tag == "connect4" else (lambda m: (int(m[0]), int(m[1])))
+            assert sorted(map(key, a)) == sorted(map(key, b))
+            other_a, other_b = ref.get_moves(player=-ref.player), mine.get_moves(player=-mine.player)
+            assert sorted(map(key, other_a)) == sorted(map(key, other_b))
+            mv = a[rng.randint(len(a))]
+            assert ref.is_legal_move(mv) and mine.is_legal_move(mv)
+            ref.play_move(mv)
+            mine.play_move(mv)
+
+
+@pytest.mark.parametrize("tag", ["othello8", "connect4", "tictactoe"])
+def test_networks_side_by_side(R, tag):
+    from alphazero_amd.games.connect4 import Connect4Net
+    from alphazero_amd.games.othello import OthelloNet
+    from alphazero_amd.games.tictactoe import TicTacToeNet
+    torch.manual_seed(4)
+    ref = {"othello8": lambda: R.oth.OthelloNet(n=8), "connect4": lambda: R.c4.Connect4Net(board_width=7, board_height=6),
+           "tictactoe": lambda: R.ttt.TicTacToeNet()}[tag]()
+    torch.manual_seed(4)
+    mine = {"othello8": lambda: OthelloNet(n=8), "connect4": lambda: Connect4Net(7, 6), "tictactoe": lambda: TicTacToeNet()}[tag]()
+    sr, sm = ref.state_dict(), mine.state_dict()
+    assert list(sr.keys()) == list(sm.keys())
+    assert all(torch.equal(sr[k], sm[k]) for k in sr)  # same layer order -> same default initialisation under one seed
+    ref.eval(); mine.eval()
+    rb, mb = _boards(R, tag)
+    x = torch.tensor(np.stack([np.asarray(rb.grid, dtype=np.float32)] * 3))
+    lp_r, v_r = ref(x)
+    lp_m, v_m = mine(x)
+    assert torch.allclose(lp_r, lp_m, atol=1e-6) and torch.allclose(v_r, v_m, atol=1e-6)
+    pr, vr = ref.evaluate(rb)  # the mirror's evaluate() runs on the HIP engine: compared in the GPU tests through G2
+    assert pr.shape[0] == mine.action_size and np.allclose(pr, np.exp(lp_m[0].detach().numpy()), atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,n_games,n_pos,sp", [("tictactoe", 512, 256, (4, 25)), ("othello6", 256, 512, (3, 25))])
+def test_committed_fixtures_are_what_the_reference_produces(R, tag, n_games, n_pos, sp, tmp_path, monkeypatch):
+    """tools/gen_golden.py re-run against the mounted reference (same plan as its main()) reproduces tests/golden/"""
+    from tools import gen_golden
+    monkeypatch.setattr(gen_golden, "GOLD", str(tmp_path))
+    positions = gen_golden.gen_rules(R, tag, n_games, seed=1000 + len(tag) + n_games, n_positions=n_pos)
+    gen_golden.gen_net(R, tag, positions)
+    gen_golden.gen_mct(R, tag, positions)
+    gen_golden.gen_selfplay(R, tag, *sp)
+    for kind in ("rules", "net", "mct", "selfplay"):
+        name = f"{kind}_{tag}.npz"
+        new = np.load(os.path.join(tmp_path, name), allow_pickle=False)
+        old = np.load(os.path.join(os.path.dirname(__file__), "golden", name), allow_pickle=False)
+        assert sorted(new.files) == sorted(old.files), name
+        for k in old.files:
+            if old[k].dtype.kind == "f":
+                assert np.allclose(new[k], old[k], rtol=0, atol=1e-6), (name, k)
+            else:
+                assert np.array_equal(new[k], old[k]), (name, k)
