@@ -51,7 +51,8 @@ struct TrunkParams {
     const float *w1f, *b1;       // conv1 B-fragment order [3 k-steps][2][64] (taps 9..11 zero), bias [32]
     const float *wf[3], *cb[3];  // conv2..4 B-fragment order [9][8][2][64], bias [32]
     const float *w1p;            // conv1, 32x32x2 B-fragment order [5 k-steps][64] (tap 9 zero)
-    const float *wp[3];          // conv2..4, 32x32x2 B-fragment order [9 taps][16 k-steps][64]
+    const float *wp[3];          // conv2..4, 32x32x2 B fragments, four k-steps per lane contiguous: [9 taps][4][64 lanes][4]
+    const float *wq[3];          // conv2..4, 16x16x4 B fragments for k_trunk2's 16-row tiles: [9 taps][4][64 lanes][4] (fragment i = 2 j + nt)
 };
 
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -260,8 +261,8 @@ struct ConvPlan {
 // tap, to the plane's spare slot (offset P_IN of every plane, kept zero) -- one address select per tile per TAP, and
 // the MFMA consumes the LDS data directly (a per-k-step value select sat on the LDS -> VALU -> MFMA critical path
 // and cost 12-25 % of conv2).
-//   wf  : 32x32x2 B fragments [9 taps][16 k-steps][64];  w0 = tap 0, preloaded by the caller
-//   wf16: 16x16x4 B fragments [9 taps][8 k-steps][2 channel tiles][64] (only read when the plan has a 16-row tile)
+//   wf  : 32x32x2 B fragments [9 taps][4][64 lanes][4 k-steps];  w0 = tap 0, preloaded by the caller
+//   wf16: 16x16x4 B fragments [9 taps][4][64 lanes][4] (fragment 2 j + nt; only read when the plan has a 16-row tile)
 template <int P_OUT, int W_OUT, int H_OUT, int IN_W, int IN_PS, int OFF1, int PAD>
 AZ_D void conv32(const float *in_lds, const float *__restrict__ wf, const float *__restrict__ wf16, const float bv, const float (&bv16)[2],
                  const float (&w0)[16], const float (&w16)[16], int lane, f32x16 (&acc)[ConvPlan<P_OUT>::MTA], f32x4 (&acc16)[2]) {
@@ -292,7 +293,7 @@ AZ_D void conv32(const float *in_lds, const float *__restrict__ wf, const float 
     unsigned vmask16 = 0;
     if (R16) ROW_SETUP(32 * MT + (lane & 15), lane >> 4, abase16, zbase16, vmask16)
 #undef ROW_SETUP
-    const float *wl = wf + lane, *wl16 = wf16 + lane;
+    const float *wl = wf + 4 * lane, *wl16 = wf16 + 4 * lane;
     float bfr[2][16], b16[2][16];  // tap 0 arrives preloaded: its L2 latency was paid under the previous layer
 #pragma unroll
     for (int i = 0; i < 16; ++i) { bfr[0][i] = w0[i]; if (R16) b16[0][i] = w16[i]; }
@@ -321,9 +322,15 @@ AZ_D void conv32(const float *in_lds, const float *__restrict__ wf, const float 
         const int tap = c / 16, j = c % 16;
         if (j == 0 && tap < 8) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                bfr[(tap + 1) & 1][i] = wl[((tap + 1) * 16 + i) * 64];
-                if (R16) b16[(tap + 1) & 1][i] = wl16[((tap + 1) * 16 + i) * 64];
+            for (int q = 0; q < 4; ++q) {  // four 16-byte loads per tap instead of sixteen dwords: VMEM issue slots are not free
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(wl + ((tap + 1) * 4 + q) * 256);
+                bfr[(tap + 1) & 1][4 * q + 0] = v[0]; bfr[(tap + 1) & 1][4 * q + 1] = v[1];
+                bfr[(tap + 1) & 1][4 * q + 2] = v[2]; bfr[(tap + 1) & 1][4 * q + 3] = v[3];
+                if (R16) {
+                    const f32x4 u = *reinterpret_cast<const f32x4 *>(wl16 + ((tap + 1) * 4 + q) * 256);
+                    b16[(tap + 1) & 1][4 * q + 0] = u[0]; b16[(tap + 1) & 1][4 * q + 1] = u[1];
+                    b16[(tap + 1) & 1][4 * q + 2] = u[2]; b16[(tap + 1) & 1][4 * q + 3] = u[3];
+                }
             }
         }
         float ac[MTA], a16 = 0.0f;
@@ -425,8 +432,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
         const size_t idx = (size_t)(pr) * (2 * G::P1) + q;                                        \
         xin[u] = (q < 2 * G::P1 && idx < (size_t)B * G::P1) ? in[idx] : 0.0f;                     \
     }
-#define LOAD_W0(l) { _Pragma("unroll") for (int i = 0; i < 16; ++i) w0[i] = tp.wp[l][lane + i * 64]; }
-#define LOAD_W16(l, PLAN) { if (PLAN::R16) { _Pragma("unroll") for (int i = 0; i < 16; ++i) w16[i] = tp.wf[l][lane + i * 64]; } }
+#define LOAD_W0(l) { _Pragma("unroll") for (int q = 0; q < 4; ++q) { const f32x4 v_ = *reinterpret_cast<const f32x4 *>(tp.wp[l] + (q * 64 + lane) * 4); \
+        w0[4 * q] = v_[0]; w0[4 * q + 1] = v_[1]; w0[4 * q + 2] = v_[2]; w0[4 * q + 3] = v_[3]; } }
+#define LOAD_W16(l, PLAN) { if (PLAN::R16) { _Pragma("unroll") for (int q = 0; q < 4; ++q) { const f32x4 v_ = *reinterpret_cast<const f32x4 *>(tp.wq[l] + (q * 64 + lane) * 4); \
+        w16[4 * q] = v_[0]; w16[4 * q + 1] = v_[1]; w16[4 * q + 2] = v_[2]; w16[4 * q + 3] = v_[3]; } } }
     LOAD_INPUT(pair)
     float w1[5], w0[16], w16[16];
 #pragma unroll
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
         {  // conv2 32->32, pad 1
             f32x16 acc[PL2::MTA];
             f32x4 acc16[2];
-            conv32<G::P1, CW, CH, CW, G::PS, OFF1, 1>(act, tp.wp[0], tp.wf[0], bv2, bq2, w0, w16, ln, acc, acc16);
+            conv32<G::P1, CW, CH, CW, G::PS, OFF1, 1>(act, tp.wp[0], tp.wq[0], bv2, bq2, w0, w16, ln, acc, acc16);
             LOAD_W0(1)
             LOAD_W16(1, PL3)
             LDS_FENCE();
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
         {  // conv3 32->32, valid
             f32x16 acc[PL3::MTA];
             f32x4 acc16[2];
-            conv32<G::P3, G::W3, G::H3, CW, G::PS, OFF1, 0>(act, tp.wp[1], tp.wf[1], bv3, bq3, w0, w16, ln, acc, acc16);
+            conv32<G::P3, G::W3, G::H3, CW, G::PS, OFF1, 0>(act, tp.wp[1], tp.wq[1], bv3, bq3, w0, w16, ln, acc, acc16);
             LOAD_W0(2)
             LOAD_W16(2, PL4)
             LDS_FENCE();
@@ -520,13 +529,29 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
         {  // conv4 32->32, valid -> flattened NCHW features
             f32x16 acc[PL4::MTA];
             f32x4 acc16[2];
-            conv32<G::P4, G::W4, G::H4, G::W3, G::PS, OFF1, 0>(act, tp.wp[2], tp.wf[2], bv4, bq4, w0, w16, ln, acc, acc16);
+            conv32<G::P4, G::W4, G::H4, G::W3, G::PS, OFF1, 0>(act, tp.wp[2], tp.wq[2], bv4, bq4, w0, w16, ln, acc, acc16);
             LOAD_W0(0)
             LOAD_W16(0, PL2)
-            conv_epilogue<G::P4>(ln, acc, acc16, [=](int r, int oc, float v) {
-                const int bd = r >= G::P4 ? 1 : 0;
-                if (bd == 0 || two) feat[(size_t)(b0 + bd) * (NCH * G::P4) + oc * G::P4 + (r - bd * G::P4)] = v;
-            });
+            if constexpr (G::P4 % 4 == 0 && !PL4::R16) {
+                // registers 4g .. 4g+3 of a tile are four consecutive positions of one board: one 16-byte store each
+#pragma unroll
+                for (int mt = 0; mt < PL4::MT; ++mt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int r0 = 32 * mt + 8 * g4 + 4 * (ln >> 5);
+                        const int bd = r0 >= G::P4 ? 1 : 0;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float x = acc[mt][4 * g4 + e]; v[e] = x > 0.0f ? x : 0.0f; }
+                        if (r0 < 2 * G::P4 && (bd == 0 || two))
+                            *reinterpret_cast<f32x4 *>(feat + (size_t)(b0 + bd) * (NCH * G::P4) + (ln & 31) * G::P4 + (r0 - bd * G::P4)) = v;
+                    }
+            } else {
+                conv_epilogue<G::P4>(ln, acc, acc16, [=](int r, int oc, float v) {
+                    const int bd = r >= G::P4 ? 1 : 0;
+                    if (bd == 0 || two) feat[(size_t)(b0 + bd) * (NCH * G::P4) + oc * G::P4 + (r - bd * G::P4)] = v;
+                });
+            }
         }
         pair = nxt;
         if (pair >= pairs) break;
@@ -943,7 +968,7 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
         NA(n->tp.w1f, 3 * 2 * 64) NA(n->tp.b1, NCH)
         for (int l = 0; l < 3; ++l) { NA(n->tp.wf[l], 9 * 8 * 2 * 64) NA(n->tp.cb[l], NCH) }
         NA(n->tp.w1p, 5 * 64)
-        for (int l = 0; l < 3; ++l) { NA(n->tp.wp[l], 9 * 16 * 64) }
+        for (int l = 0; l < 3; ++l) { NA(n->tp.wp[l], 9 * 16 * 64) NA(n->tp.wq[l], 9 * 16 * 64) }
         NA(n->fc1w, (size_t)n->FIN * n->F1) NA(n->fc1b, n->F1) NA(n->fc2w, (size_t)n->F1 * n->F2) NA(n->fc2b, n->F2)
         NA(n->hw, (size_t)n->F2 * n->NH) NA(n->hb, n->NH)
         NA(n->feat, (size_t)max_batch * n->FIN) NA(n->h1, (size_t)max_batch * n->F1) NA(n->h2, (size_t)max_batch * n->F2)
@@ -1073,15 +1098,25 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
                             fw[((t * 8 + j) * 2 + nt) * 64 + lane] = (float)((double)(*w)[(oc * NCH + ic) * 9 + t] * s[oc]);
                         }
             AZ_TRY(upload((float *)n->tp.wf[l - 1], fw, st)); AZ_TRY(upload((float *)n->tp.cb[l - 1], fb, st));
-            // 32x32x2 B-fragment order: [tap][j][lane] = W'[oc = lane&31][ic = 2j + (lane>>5)][tap]
+            // 32x32x2 B fragments, [tap][j / 4][lane][j % 4] = W'[oc = lane&31][ic = 2j + (lane>>5)][tap]: a lane fetches the
+            // fragments of four consecutive k-steps with one 16-byte load
             std::vector<float> fp(9 * 16 * 64);
             for (int t = 0; t < 9; ++t)
                 for (int j = 0; j < 16; ++j)
                     for (int lane = 0; lane < 64; ++lane) {
                         int oc = lane & 31, ic = 2 * j + (lane >> 5);
-                        fp[(t * 16 + j) * 64 + lane] = (float)((double)(*w)[(oc * NCH + ic) * 9 + t] * s[oc]);
+                        fp[((t * 4 + j / 4) * 64 + lane) * 4 + j % 4] = (float)((double)(*w)[(oc * NCH + ic) * 9 + t] * s[oc]);
                     }
             AZ_TRY(upload((float *)n->tp.wp[l - 1], fp, st));
+            // the same for the 16x16x4 fragments of k_trunk2's 16-row tiles: fragment i = 2 j8 + nt at [tap][i / 4][lane][i % 4]
+            for (int t = 0; t < 9; ++t)
+                for (int j = 0; j < 8; ++j)
+                    for (int nt = 0; nt < 2; ++nt)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            int oc = nt * 16 + (lane & 15), ic = 4 * j + (lane >> 4), i = 2 * j + nt;
+                            fp[((t * 4 + i / 4) * 64 + lane) * 4 + i % 4] = (float)((double)(*w)[(oc * NCH + ic) * 9 + t] * s[oc]);
+                        }
+            AZ_TRY(upload((float *)n->tp.wq[l - 1], fp, st));
         }
     }
     {
