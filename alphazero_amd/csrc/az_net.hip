@@ -49,10 +49,10 @@ __device__ unsigned long long az_probe_buf[8192 * 8];
 
 struct TrunkParams {
     const float *w1f, *b1;       // conv1 B-fragment order [3 k-steps][2][64] (taps 9..11 zero), bias [32]
-    const float *wf[3], *cb[3];  // conv2..4 B-fragment order [9][8][2][64], bias [32]
+    const float *cb[3];          // conv2..4 folded bias [32]
     const float *w1p;            // conv1, 32x32x2 B-fragment order [5 k-steps][64] (tap 9 zero)
     const float *wp[3];          // conv2..4, 32x32x2 B fragments, four k-steps per lane contiguous: [9 taps][4][64 lanes][4]
-    const float *wq[3];          // conv2..4, 16x16x4 B fragments for k_trunk2's 16-row tiles: [9 taps][4][64 lanes][4] (fragment i = 2 j + nt)
+    const float *wq[3];          // conv2..4, 16x16x4 B fragments (k_trunk; k_trunk2's 16-row tiles): [9 taps][4][64 lanes][4] (fragment i = 2 j + nt)
 };
 
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -85,10 +85,13 @@ AZ_D void conv_mfma(const float *in_lds, const float *__restrict__ wf, const flo
         }
         vmask[mt] = vm;
     }
-    const float *wl = wf + lane;
+    const float *wl = wf + 4 * lane;  // fragment i = 2 j + nt of a tap sits at [tap][i / 4][lane][i % 4]: 16-byte loads
     float bfr[2][16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bfr[0][i] = wl[i * 64];
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(wl + q * 256);
+        bfr[0][4 * q] = v[0]; bfr[0][4 * q + 1] = v[1]; bfr[0][4 * q + 2] = v[2]; bfr[0][4 * q + 3] = v[3];
+    }
     const float bv0 = bias[m_lane], bv1 = bias[16 + m_lane];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -106,7 +109,11 @@ AZ_D void conv_mfma(const float *in_lds, const float *__restrict__ wf, const flo
         const int tap = c / 8, j = c % 8;
         if (j == 0 && tap < 8) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bfr[(tap + 1) & 1][i] = wl[((tap + 1) * 16 + i) * 64];
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(wl + ((tap + 1) * 4 + q) * 256);
+                bfr[(tap + 1) & 1][4 * q] = v[0]; bfr[(tap + 1) & 1][4 * q + 1] = v[1];
+                bfr[(tap + 1) & 1][4 * q + 2] = v[2]; bfr[(tap + 1) & 1][4 * q + 3] = v[3];
+            }
         }
         float ac[MT];
 #pragma unroll
@@ -205,21 +212,21 @@ __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, 
     LDS_FENCE();
     {  // conv2 32->32, pad 1 (othello.py:371)
         f32x4 acc[G::MT2][2];
-        conv_mfma<G::P1, CW, CH, CW, G::PS, 1, G::MT2>(act, tp.wf[0], tp.cb[0], lane, acc);
+        conv_mfma<G::P1, CW, CH, CW, G::PS, 1, G::MT2>(act, tp.wq[0], tp.cb[0], lane, acc);
         LDS_FENCE();
         store_relu_lds<G::P1, G::PS, G::MT2>(act, lane, acc);
     }
     LDS_FENCE();
     {  // conv3 32->32, valid (othello.py:372)
         f32x4 acc[G::MT3][2];
-        conv_mfma<G::P3, G::W3, G::H3, CW, G::PS, 0, G::MT3>(act, tp.wf[1], tp.cb[1], lane, acc);
+        conv_mfma<G::P3, G::W3, G::H3, CW, G::PS, 0, G::MT3>(act, tp.wq[1], tp.cb[1], lane, acc);
         LDS_FENCE();
         store_relu_lds<G::P3, G::PS, G::MT3>(act, lane, acc);
     }
     LDS_FENCE();
     {  // conv4 32->32, valid (othello.py:373) -> flattened NCHW features (othello.py:374)
         f32x4 acc[G::MT4][2];
-        conv_mfma<G::P4, G::W4, G::H4, G::W3, G::PS, 0, G::MT4>(act, tp.wf[2], tp.cb[2], lane, acc);
+        conv_mfma<G::P4, G::W4, G::H4, G::W3, G::PS, 0, G::MT4>(act, tp.wq[2], tp.cb[2], lane, acc);
         float *fo = feat + (size_t)b * (NCH * G::P4);
 #pragma unroll
         for (int mt = 0; mt < G::MT4; ++mt)
@@ -966,7 +973,7 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
         float *p;
 #define NA(field, cnt) if (rc == AZ_OK) { rc = net_alloc(n, &p, (cnt)); field = p; }
         NA(n->tp.w1f, 3 * 2 * 64) NA(n->tp.b1, NCH)
-        for (int l = 0; l < 3; ++l) { NA(n->tp.wf[l], 9 * 8 * 2 * 64) NA(n->tp.cb[l], NCH) }
+        for (int l = 0; l < 3; ++l) { NA(n->tp.cb[l], NCH) }
         NA(n->tp.w1p, 5 * 64)
         for (int l = 0; l < 3; ++l) { NA(n->tp.wp[l], 9 * 16 * 64) NA(n->tp.wq[l], 9 * 16 * 64) }
         NA(n->fc1w, (size_t)n->FIN * n->F1) NA(n->fc1b, n->F1) NA(n->fc2w, (size_t)n->F1 * n->F2) NA(n->fc2b, n->F2)
@@ -1088,16 +1095,7 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
                 }
             AZ_TRY(upload((float *)n->tp.w1p, fp, st));
         } else {
-            // MFMA B-fragment order: [tap][j][nt][lane] = W'[oc = nt*16 + (lane&15)][ic = 4j + (lane>>4)][tap]
-            std::vector<float> fw(9 * 8 * 2 * 64);
-            for (int t = 0; t < 9; ++t)
-                for (int j = 0; j < 8; ++j)
-                    for (int nt = 0; nt < 2; ++nt)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            int oc = nt * 16 + (lane & 15), ic = 4 * j + (lane >> 4);
-                            fw[((t * 8 + j) * 2 + nt) * 64 + lane] = (float)((double)(*w)[(oc * NCH + ic) * 9 + t] * s[oc]);
-                        }
-            AZ_TRY(upload((float *)n->tp.wf[l - 1], fw, st)); AZ_TRY(upload((float *)n->tp.cb[l - 1], fb, st));
+            AZ_TRY(upload((float *)n->tp.cb[l - 1], fb, st));
             // 32x32x2 B fragments, [tap][j / 4][lane][j % 4] = W'[oc = lane&31][ic = 2j + (lane>>5)][tap]: a lane fetches the
             // fragments of four consecutive k-steps with one 16-byte load
             std::vector<float> fp(9 * 16 * 64);
@@ -1108,7 +1106,8 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
                         fp[((t * 4 + j / 4) * 64 + lane) * 4 + j % 4] = (float)((double)(*w)[(oc * NCH + ic) * 9 + t] * s[oc]);
                     }
             AZ_TRY(upload((float *)n->tp.wp[l - 1], fp, st));
-            // the same for the 16x16x4 fragments of k_trunk2's 16-row tiles: fragment i = 2 j8 + nt at [tap][i / 4][lane][i % 4]
+            // the same for the 16x16x4 fragments (k_trunk, and k_trunk2's 16-row tiles): fragment i = 2 j8 + nt at
+            // [tap][i / 4][lane][i % 4] = W'[oc = nt*16 + (lane&15)][ic = 4 j8 + (lane>>4)][tap]
             for (int t = 0; t < 9; ++t)
                 for (int j = 0; j < 8; ++j)
                     for (int nt = 0; nt < 2; ++nt)
