@@ -61,9 +61,11 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    so = os.path.join(_HERE, "liboracle.so")
-    if not os.path.exists(so):
-        build()
+    so = os.environ.get("AZ_ORACLE_LIB")  # e.g. an AddressSanitizer build of az_oracle.c (CPU only)
+    if not so:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
     L = C.CDLL(so)
     bp = C.POINTER(Board)
     L.orc_board_init.argtypes = [bp, C.c_int, C.c_int, C.c_int]
