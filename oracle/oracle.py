@@ -192,9 +192,12 @@ class ConvNet:
         return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_convnet_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().orc_convnet_destroy(self.h)
+                self.h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class MlpNet:

@@ -32,7 +32,9 @@ def forward_unfold(self, input):
     return F.log_softmax(self.fc_probs(x), dim=1), torch.tanh(self.fc_value(x))
 
 
-for name, fwd in (("MIOpen conv", None), ("im2col + GEMM", forward_unfold)):
+if os.environ.get("AZ_CUDNN_BENCHMARK") == "1":
+    torch.backends.cudnn.benchmark = True
+for name, fwd in (("MIOpen conv", None),):
     torch.manual_seed(0)
     net = OthelloNet(n=8, device="cuda").train()
     if fwd is not None:
