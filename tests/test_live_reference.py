@@ -94,3 +94,26 @@ def test_committed_fixtures_are_what_the_reference_produces(R, tag, n_games, n_p
                 assert np.allclose(new[k], old[k], rtol=0, atol=1e-6), (name, k)
             else:
                 assert np.array_equal(new[k], old[k]), (name, k)
+
+
+def test_checkpoints_cross_load(R, tmp_path):
+    """checkpoint wire format (base.py:288-325, trainer.py:448-473): models/<name>/{config.json,<name>.pt} written by either
+    side load into the other and give the same network"""
+    import json
+    from alphazero_amd.games.othello import OthelloConfig, OthelloNet
+    torch.manual_seed(2)
+    mine = OthelloNet(config=OthelloConfig(board_size=6))
+    d = os.path.join(tmp_path, "m1")
+    mine.save_model("m1", model_path=d)
+    json.dump(OthelloConfig(board_size=6).to_dict(), open(os.path.join(d, "config.json"), "w"))
+    ref = R.oth.OthelloNet.from_pretrained("m1", models_path=str(tmp_path))
+    assert all(torch.equal(v, ref.state_dict()[k]) for k, v in mine.state_dict().items())
+    # the other way round: the reference writes, the mirror reads
+    torch.manual_seed(3)
+    ref2 = R.oth.OthelloNet(config=R.oth.OthelloConfig(board_size=6))
+    d2 = os.path.join(tmp_path, "m2")
+    ref2.save_model("m2", model_path=d2)
+    json.dump(R.oth.OthelloConfig(board_size=6).to_dict(), open(os.path.join(d2, "config.json"), "w"))
+    mine2 = OthelloNet.from_pretrained("m2", models_path=str(tmp_path))
+    assert all(torch.equal(v, mine2.state_dict()[k]) for k, v in ref2.state_dict().items())
+    assert mine2.n == 6 and sorted(OthelloConfig(board_size=6).to_dict()) == sorted(R.oth.OthelloConfig(board_size=6).to_dict())
