@@ -150,6 +150,8 @@ def main():
         full = [hnet.time_stage(s, G, iters=20) for s in range(4)]  # context: one launch at the full batch
         out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                           "traffic_is_for": f"one launch at the full batch of {G} boards (PMC passes run tools/prof_net.py); "
+                                             f"algorithmic bytes of that launch: {G * (n * n * 4 + 32 * (n - 4) ** 2 * 4)}",
                            "launches": prof[kname][1], "avg_launch_ms": prof[kname][0] / max(1, prof[kname][1]),
                            "avg_boards_per_launch": evals_total / max(1, prof[kname][1] + (prof["k_trunk"][1] if dom == 0 else 0)),
                            "algorithmic_flops_per_board": fl[dom], "boards_evaluated": evals_total,
