@@ -25,6 +25,7 @@
 // them.  This stores n_children priors per evaluated node instead of the raw probs[A] vector.
 #include <string.h>
 
+#include <map>
 #include <vector>
 
 #include "az_device.h"
@@ -1022,6 +1023,15 @@ struct az_engine {
     int *h_err;                 // pinned [2] : err, max_nodes
     long long lockstep_iters;
     u32 sim_base = 0;
+    // The engine runs on a stream of its own (graph capture is not allowed on the legacy default stream); every entry
+    // point first orders it behind the caller's stream and returns only after its own stream has drained.
+    hipStream_t user_stream = nullptr;
+    hipEvent_t ev_in = nullptr;
+    // One search = 1 + 5 n_sim kernel launches: captured once per (n_sim, batch cap) as a HIP graph and replayed
+    std::map<unsigned long long, hipGraphExec_t> graphs;
+    std::map<unsigned long long, int> graph_seen;
+    bool graphs_ok = true;
+    long long graph_replays = 0;
     int active_bound = 0;  // upper bound on the slots still searching (known per ply): caps the network batch, which picks the kernels
 };
 
@@ -1075,7 +1085,14 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
                    az_net_action_size(net), gd.A);
     az_engine *e = new az_engine();
     e->h_ctr = nullptr; e->h_err = nullptr;
-    e->cfg = *cfg; e->net = net; e->stream = (hipStream_t)stream; e->lockstep_iters = 0;
+    e->cfg = *cfg; e->net = net; e->user_stream = (hipStream_t)stream; e->stream = nullptr; e->lockstep_iters = 0;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming) != hipSuccess) {
+        az_engine_destroy(e);
+        az_set_error("could not create the engine's stream");
+        return AZ_EHIP;
+    }
+    { const char *g = getenv("AZ_ENGINE_GRAPHS"); if (g && atoi(g) == 0) e->graphs_ok = false; }
     EngDev &d = e->d;
     d.gd = gd; d.G = cfg->n_slots; d.C = cfg->node_capacity; d.A = gd.A; d.max_plies = cfg->max_plies;
     d.alpha = cfg->dirichlet_alpha; d.eps = cfg->dirichlet_epsilon; d.tie_mode = cfg->tie_mode;
@@ -1104,47 +1121,95 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
 
 extern "C" void az_engine_destroy(az_engine *e) {
     if (!e) return;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void *p : e->allocs) (void)hipFree(p);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);
     if (e->h_err) (void)hipHostFree(e->h_err);
     delete e;
 }
 
 // network over the compacted leaf rows [0, *cnt)
-static int forward(az_engine *e, const int *cnt) {
+static int forward(az_engine *e, const int *cnt, int cap) {
     EngDev &d = e->d;
     if (e->cfg.evaluator == AZ_EVAL_FAKE) {
         hipLaunchKernelGGL(k_fakenet, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, cnt);
         return AZ_OK;
     }
-    const int cap = e->active_bound > 0 && e->active_bound < d.G ? e->active_bound : d.G;  // leaf rows are compact: count <= searching slots
     return az_net_forward_dyn(e->net, d.nn_in, cnt, cap, d.probs, d.value, e->stream);
 }
 
 // MCT.search for every active slot: one root-prior pass (mcts.py:231-233; empty unless a slot holds a
 // fresh root), then n_sim lock-steps of [backup+select -> network].
-static int do_search(az_engine *e, int n_sim) {
+// the raw launch sequence of one search; `cap` bounds the network batch (leaf rows are compact: count <= searching slots)
+static int enqueue_search(az_engine *e, int n_sim, int cap) {
     EngDev &d = e->d;
     dim3 gg((unsigned)((d.G + GPB - 1) / GPB)), gb(256);
-    d.sim_base = e->sim_base;
-    e->sim_base += (u32)n_sim;
     if (d.rollout) {  // no network: one launch per simulation
         for (int s = 0; s < n_sim; ++s) hipLaunchKernelGGL(k_rollout_step, gg, gb, 0, e->stream, d, s);
-        e->lockstep_iters += n_sim;
         AZ_HIP(hipGetLastError());
         return AZ_OK;
     }
     hipLaunchKernelGGL(k_root_prep, gg, gb, 0, e->stream, d, 0, d.G);
-    AZ_TRY(forward(e, d.batch_cnt + 2));
+    AZ_TRY(forward(e, d.batch_cnt + 2, cap));
     hipLaunchKernelGGL(k_root_init, gg, gb, 0, e->stream, d, 0, d.G);
     for (int s = 0; s < n_sim; ++s) {
         if (s == 0) hipLaunchKernelGGL((k_step<false, true>), gg, gb, 0, e->stream, d, s, 0, d.G);
         else hipLaunchKernelGGL((k_step<true, true>), gg, gb, 0, e->stream, d, s, 0, d.G);
-        AZ_TRY(forward(e, d.batch_cnt + (s & 1)));
+        AZ_TRY(forward(e, d.batch_cnt + (s & 1), cap));
     }
     hipLaunchKernelGGL((k_step<true, false>), gg, gb, 0, e->stream, d, n_sim, 0, d.G);
-    e->lockstep_iters += n_sim + 1;
     AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+static int do_search(az_engine *e, int n_sim) {
+    EngDev &d = e->d;
+    d.sim_base = e->sim_base;
+    e->sim_base += (u32)n_sim;
+    e->lockstep_iters += d.rollout ? n_sim : n_sim + 1;
+    int cap = e->active_bound > 0 && e->active_bound < d.G ? e->active_bound : d.G;
+    // graph replay needs launch parameters that do not change from search to search: the Philox counter base must be 0
+    // (one search per root, as in self-play and the arena), no per-launch event recording, and a quantised batch cap
+    const bool graphable = e->graphs_ok && d.sim_base == 0 && !(e->net && az_net_profiling(e->net));
+    if (!graphable) return enqueue_search(e, n_sim, cap);
+    cap = (d.G >= 4096 && cap < 4096) ? (cap + 511) / 512 * 512 : d.G;  // below 4096 rows the network picks other kernels
+    const unsigned long long key = ((unsigned long long)n_sim << 32) | (unsigned)cap;
+    auto it = e->graphs.find(key);
+    if (it != e->graphs.end()) {
+        AZ_HIP(hipGraphLaunch(it->second, e->stream));
+        e->graph_replays++;
+        return AZ_OK;
+    }
+    if (e->graph_seen[key]++ == 0) return enqueue_search(e, n_sim, cap);  // first time: plain launches (kernel attributes get set)
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ex = nullptr;
+    if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        e->graphs_ok = false;
+        return enqueue_search(e, n_sim, cap);
+    }
+    const int rc = enqueue_search(e, n_sim, cap);  // recorded, not executed
+    const hipError_t er = hipStreamEndCapture(e->stream, &g);
+    if (rc != AZ_OK || er != hipSuccess || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (g) (void)hipGraphDestroy(g);
+        e->graphs_ok = false;
+        return enqueue_search(e, n_sim, cap);
+    }
+    (void)hipGraphDestroy(g);
+    e->graphs[key] = ex;
+    AZ_HIP(hipGraphLaunch(ex, e->stream));
+    e->graph_replays++;
+    return AZ_OK;
+}
+
+// orders the engine's stream behind whatever the caller has queued on the stream it handed to az_engine_create
+static int enter(az_engine *e) {
+    AZ_HIP(hipEventRecord(e->ev_in, e->user_stream));
+    AZ_HIP(hipStreamWaitEvent(e->stream, e->ev_in, 0));
     return AZ_OK;
 }
 
@@ -1167,6 +1232,7 @@ static int check_err(az_engine *e) {
 
 extern "C" int az_engine_run(az_engine *e, uint32_t first_game_id, int32_t n_games) {
     AZ_REQUIRE(e && n_games > 0, AZ_EINVAL, "bad arguments");
+    AZ_TRY(enter(e));
     EngDev &d = e->d;
     e->lockstep_iters = 0;
     hipLaunchKernelGGL(k_reset_all, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, (u32)first_game_id, (int)n_games);
@@ -1191,6 +1257,7 @@ extern "C" int az_engine_run(az_engine *e, uint32_t first_game_id, int32_t n_gam
 
 extern "C" int az_engine_get_stats(az_engine *e, az_engine_stats *out) {
     AZ_REQUIRE(e && out, AZ_EINVAL, "null argument");
+    AZ_TRY(enter(e));
     AZ_TRY(fetch_counters(e));
     out->games_done = (int64_t)e->h_ctr[CTR_GAMES_DONE];
     long long s = (long long)e->h_ctr[CTR_SAMPLES];
@@ -1200,6 +1267,7 @@ extern "C" int az_engine_get_stats(az_engine *e, az_engine_stats *out) {
     out->lockstep_iters = e->lockstep_iters;
     out->max_nodes_used = e->h_err[1];
     out->error_flags = e->h_err[0];
+    out->graph_replays = e->graph_replays;
     return AZ_OK;
 }
 
@@ -1223,6 +1291,7 @@ extern "C" int az_engine_set_roots(az_engine *e, const int8_t *h_grids, const in
     AZ_REQUIRE(e && h_grids && h_players, AZ_EINVAL, "null argument");
     EngDev &d = e->d;
     AZ_REQUIRE(n_roots > 0 && n_roots <= d.G, AZ_EINVAL, "n_roots must be in [1, n_slots]");
+    AZ_TRY(enter(e));
     e->active_bound = n_roots;
     hipLaunchKernelGGL(k_reset_all, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, 0u, (int)n_roots);
     std::vector<u64> p1(n_roots), m1(n_roots);
@@ -1253,6 +1322,7 @@ extern "C" int az_engine_set_roots(az_engine *e, const int8_t *h_grids, const in
 
 extern "C" int az_engine_search(az_engine *e, int32_t n_sim) {
     AZ_REQUIRE(e && n_sim > 0, AZ_EINVAL, "bad arguments");
+    AZ_TRY(enter(e));
     AZ_TRY(do_search(e, n_sim));
     AZ_TRY(fetch_counters(e));
     return check_err(e);

@@ -1309,6 +1309,8 @@ extern "C" int az_net_profile(az_net *n, int enable) {
     return AZ_OK;
 }
 
+extern "C" int az_net_profiling(const az_net *n) { return n && n->prof ? 1 : 0; }
+
 extern "C" int az_net_profile_read(az_net *n, double *ms_total, int64_t *launches) {
     AZ_REQUIRE(n && ms_total && launches, AZ_EINVAL, "null argument");
     AZ_TRY(prof_harvest(n));

@@ -96,6 +96,7 @@ int az_net_time_stage(az_net *net, int stage, int B, int iters, void *stream, fl
  * launches with HIP events on its own stream.  ms_total[5] / launches[5]: k_trunk2, k_gemm fc1, k_gemm fc2, k_heads,
  * k_trunk (one board per wave, small batches). */
 int az_net_profile(az_net *net, int enable);
+int az_net_profiling(const az_net *net); /* 1 while enabled (the engine then launches kernel by kernel instead of replaying graphs) */
 int az_net_profile_read(az_net *net, double *ms_total, int64_t *launches);
 
 /* ---- self-play engine (K3/K4/K7/K8/K9) -------------------------------------------------------
@@ -119,8 +120,13 @@ typedef struct {
 typedef struct {
     int64_t games_done, samples, net_evals, lockstep_iters, plies;
     int32_t max_nodes_used, error_flags;
+    int64_t graph_replays;  /* searches issued as one HIP graph launch since the engine was created */
 } az_engine_stats;
 
+/* `stream` (hipStream_t, may be the default stream): the stream the caller's own work is queued on.  The engine runs on a
+ * stream of its own: every call first orders that stream behind `stream` and returns only when the engine's work is done.
+ * One search (1 + 5 n_sim launches) is captured as a HIP graph the second time it is issued with the same shape and
+ * replayed from then on (AZ_ENGINE_GRAPHS=0 in the environment switches that off). */
 int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *stream, az_engine **out);
 void az_engine_destroy(az_engine *e);
 /* plays games first_game_id .. first_game_id+n_games-1 to completion (slots are refilled as games

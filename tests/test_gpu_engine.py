@@ -226,3 +226,27 @@ def test_results_do_not_depend_on_the_batch_shape():
     assert len(a["z"]) == len(b["z"])
     for k in ("state", "z", "meta", "visits", "pi"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_searches_are_replayed_as_hip_graphs():
+    """a search (1 + 5 n_sim launches) is captured the second time it is issued with the same shape and replayed from
+    then on; the samples do not depend on it"""
+    import os
+    import subprocess
+    import sys
+    game, gid, H, W, A, n = TAGS["othello6"]
+    eng = E.SelfPlayEngine(gid, H, W, n_slots=32, n_sim=20, evaluator=E.EVAL_FAKE, seed=1, node_capacity=8192)
+    a = sort_samples(eng.run(32))
+    st = eng.stats()
+    assert st["graph_replays"] >= st["plies"] // 32 - 2 > 10  # every ply but the first two
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import numpy as np\n"
+            "from alphazero_amd import engine as E\nfrom test_gpu_engine import sort_samples\n"
+            "eng = E.SelfPlayEngine(%d, %d, %d, n_slots=32, n_sim=20, evaluator=E.EVAL_FAKE, seed=1, node_capacity=8192)\n"
+            "s = sort_samples(eng.run(32)); assert eng.stats()['graph_replays'] == 0\n"
+            "np.savez(sys.argv[1], **s)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), gid, H, W)
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "az_nograph_%d.npz" % os.getpid())
+    subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, AZ_ENGINE_GRAPHS="0"))
+    b = np.load(out)
+    os.remove(out)
+    for k in ("state", "z", "meta", "visits", "pi"):
+        assert np.array_equal(a[k], b[k]), k
