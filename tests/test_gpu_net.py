@@ -73,17 +73,19 @@ def test_full_batch_and_ragged():
 def test_large_batch_kernel_equals_small_batch_kernel(tag):
     """from 4096 boards up the trunk runs two boards per wave on 32x32x2 MFMA (k_trunk2), below that one board per
     wave on 16x16x4: same accumulation order, so the same boards must give the same bits in either -- odd and ragged
-    batch sizes included (the small-batch results are the ones checked against the oracle above)"""
+    batch sizes included (the small-batch results are the ones checked against the oracle above).  The dense layers
+    switch tile shapes with the batch as well (128x128 from 8192 / 16384 rows)."""
     game, gid, H, W, A, n = TAGS[tag]
     fx, sd, onet, _ = nets(tag)
-    hnet = E.HipNet(gid, H, W, sd, max_batch=9000)
+    sizes = (4096, 4099, 6001, 9000) + ((16500,) if tag == "othello8" else ())  # 16500: both dense layers on the 128x128 GEMM tile
+    hnet = E.HipNet(gid, H, W, sd, max_batch=max(sizes))
     grids, players, _ = O.random_positions(gid, H, W, 11, 40, 1200)
     canon = torch.as_tensor((grids * players[:, None]).astype(np.float32), device="cuda")
     n0 = canon.shape[0]
     p_ref, v_ref = hnet.forward(canon)  # < 4096 rows: one board per wave
     op, ov = onet.forward(canon.cpu().numpy()[:200])
     assert np.array_equal(p_ref.cpu().numpy()[:200], op) and np.array_equal(v_ref.cpu().numpy()[:200], ov)
-    for B in (4096, 4099, 6001, 9000):
+    for B in sizes:
         idx = torch.arange(B, device="cuda") % n0
         idx = (idx * 7 + 3) % n0  # not the same neighbour pairs in every pass
         p, v = hnet.forward(canon[idx].contiguous())
