@@ -427,7 +427,21 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
     if (threadIdx.x < 4) ticket_ctr[threadIdx.x] = 0;
     __syncthreads();  // the only workgroup barrier: the waves are independent from here on
     const int simd = (__builtin_amdgcn_s_getreg((4 << 11) | (4 << 6) | 4) & 3);  // HW_REG_HW_ID bits [5:4]
-#define NEXT_TICKET(var) { int t_ = 0; if (lane == 0) t_ = atomicAdd(ticket_ctr + simd, 1); var = 4 * (int)blockIdx.x + simd + __builtin_amdgcn_readfirstlane(t_) * 4 * (int)gridDim.x; }
+    // a wave draws from its own SIMD's queue and, once that is empty, from the other three: every pair is processed
+    // whatever the hardware reports as SIMD id, and a SIMD that ran ahead helps out at the end
+    int qoff = 0;
+#define NEXT_TICKET(var)                                                                                                   \
+    {                                                                                                                      \
+        var = pairs;                                                                                                       \
+        while (qoff < 4) {                                                                                                 \
+            const int q_ = (simd + qoff) & 3;                                                                              \
+            int t_ = 0;                                                                                                    \
+            if (lane == 0) t_ = atomicAdd(ticket_ctr + q_, 1);                                                             \
+            var = 4 * (int)blockIdx.x + q_ + __builtin_amdgcn_readfirstlane(t_) * 4 * (int)gridDim.x;                      \
+            if (var < pairs) break;                                                                                        \
+            ++qoff;                                                                                                        \
+        }                                                                                                                  \
+    }
     int pair;
     NEXT_TICKET(pair)
     if (pair >= pairs) return;
