@@ -1032,6 +1032,8 @@ struct az_engine {
     std::map<unsigned long long, int> graph_seen;
     bool graphs_ok = true;
     long long graph_replays = 0;
+    int *scr_a = nullptr, *scr_b = nullptr;  // [G] int scratch of the arena entry points (moves in/out, status, scores)
+    char *scr_c = nullptr;                   // [3 G] bytes
     int active_bound = 0;  // upper bound on the slots still searching (known per ply): caps the network batch, which picks the kernels
 };
 
@@ -1111,6 +1113,9 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
     A_(o_state, S * gd.cells); A_(o_pi, S * gd.A); A_(o_z, S); A_(o_meta, S * 4); A_(o_visits, S * gd.A);
     A_(ctr, CTR_COUNT); A_(err, 1); A_(max_nodes, 1);
 #undef A_
+    if (rc == AZ_OK) rc = dev_alloc(e, &e->scr_a, G);
+    if (rc == AZ_OK) rc = dev_alloc(e, &e->scr_b, G);
+    if (rc == AZ_OK) rc = dev_alloc(e, &e->scr_c, 3 * G);
     if (rc == AZ_OK && hipHostMalloc((void **)&e->h_ctr, sizeof(unsigned long long) * CTR_COUNT) != hipSuccess) rc = AZ_EHIP;
     if (rc == AZ_OK && hipHostMalloc((void **)&e->h_err, sizeof(int) * 2) != hipSuccess) rc = AZ_EHIP;
     if (rc != AZ_OK) { az_engine_destroy(e); return rc; }
@@ -1372,15 +1377,12 @@ extern "C" int az_engine_play(az_engine *e, const int32_t *h_actions, int32_t n,
     AZ_REQUIRE(e && h_actions && h_status, AZ_EINVAL, "null argument");
     EngDev &d = e->d;
     AZ_REQUIRE(n > 0 && n <= d.G, AZ_EINVAL, "n must be in [1, n_slots]");
-    int *d_act = nullptr, *d_st = nullptr;
-    AZ_HIP(hipMalloc((void **)&d_act, sizeof(int) * n));
-    AZ_HIP(hipMalloc((void **)&d_st, sizeof(int) * n));
+    int *d_act = e->scr_a, *d_st = e->scr_b;
     AZ_HIP(hipMemcpyAsync(d_act, h_actions, sizeof(int) * n, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_apply_moves, grid_for(n, TB), dim3(TB), 0, e->stream, d, d_act, (int)n, d_st);
     hipLaunchKernelGGL(k_reroot, dim3((unsigned)((d.G + GPB - 1) / GPB)), dim3(256), 0, e->stream, d);
     AZ_HIP(hipMemcpyAsync(h_status, d_st, sizeof(int) * n, hipMemcpyDeviceToHost, e->stream));
     AZ_HIP(hipStreamSynchronize(e->stream));
-    (void)hipFree(d_act); (void)hipFree(d_st);
     for (int i = 0; i < n; ++i)
         if (h_status[i] == AZ_EILLEGAL) { az_set_error("Illegal move %d for slot %d", h_actions[i], i); return AZ_EILLEGAL; }
     AZ_TRY(fetch_counters(e));
@@ -1404,13 +1406,11 @@ extern "C" int az_engine_set_sides(az_engine *e, const int8_t *h_sides, int32_t 
 
 static int moves_out(az_engine *e, int32_t *h_actions, int which, int kind, uint32_t seed) {
     EngDev &d = e->d;
-    int *d_act = nullptr;
-    AZ_HIP(hipMalloc((void **)&d_act, sizeof(int) * d.G));
+    int *d_act = e->scr_a;
     if (which == 0) hipLaunchKernelGGL(k_best_moves, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, d_act);
     else hipLaunchKernelGGL(k_baseline_moves, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, kind, (u32)seed, d_act);
     AZ_HIP(hipMemcpyAsync(h_actions, d_act, sizeof(int) * d.G, hipMemcpyDeviceToHost, e->stream));
     AZ_HIP(hipStreamSynchronize(e->stream));
-    (void)hipFree(d_act);
     return AZ_OK;
 }
 
@@ -1427,18 +1427,15 @@ extern "C" int az_engine_baseline_moves(az_engine *e, int32_t kind, uint32_t see
 extern "C" int az_engine_root_status(az_engine *e, int8_t *h_players, uint8_t *h_over, int8_t *h_winner, int32_t *h_score) {
     AZ_REQUIRE(e && h_players && h_over && h_winner && h_score, AZ_EINVAL, "null argument");
     EngDev &d = e->d;
-    char *buf = nullptr;
+    char *buf = e->scr_c;
     size_t G = d.G;
-    AZ_HIP(hipMalloc((void **)&buf, G * 7));
     int8_t *pl = (int8_t *)buf; uint8_t *ov = (uint8_t *)(buf + G); int8_t *wi = (int8_t *)(buf + 2 * G);
-    int *sc = nullptr;
-    AZ_HIP(hipMalloc((void **)&sc, G * sizeof(int)));
+    int *sc = e->scr_a;
     hipLaunchKernelGGL(k_root_status, grid_for(d.G, TB), dim3(TB), 0, e->stream, d, pl, ov, wi, sc);
     AZ_HIP(hipMemcpyAsync(h_players, pl, G, hipMemcpyDeviceToHost, e->stream));
     AZ_HIP(hipMemcpyAsync(h_over, ov, G, hipMemcpyDeviceToHost, e->stream));
     AZ_HIP(hipMemcpyAsync(h_winner, wi, G, hipMemcpyDeviceToHost, e->stream));
     AZ_HIP(hipMemcpyAsync(h_score, sc, G * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     AZ_HIP(hipStreamSynchronize(e->stream));
-    (void)hipFree(buf); (void)hipFree(sc);
     return AZ_OK;
 }
