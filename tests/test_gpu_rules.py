@@ -116,3 +116,23 @@ def test_empty_and_error_inputs():
     assert E.legal_batch(0, 8, 8, g, p).shape == (0, 65)
     with pytest.raises(ValueError, match="even"):
         E.legal_batch(0, 7, 7, g, p)
+
+
+@pytest.mark.parametrize("H,W", [(4, 4), (8, 8), (5, 6), (6, 8), (8, 5)])
+def test_connect4_other_board_sizes(H, W):
+    """Connect4 boards from the minimum 4x4 (connect4.py:90-91) to the 8x8 maximum of the bitboards, non-square included"""
+    gid = O.CONNECT4
+    grids, players, actions = O.random_positions(gid, H, W, 3 + H * 8 + W, 3000, 200000)
+    assert len(players) > 15000
+    dg = torch.as_tensor(grids.reshape(-1, H, W), device="cuda")
+    dp = torch.as_tensor(players, device="cuda")
+    assert np.array_equal(E.legal_batch(gid, H, W, dg, dp).cpu().numpy(), O.batch_legal(gid, H, W, grids, players))
+    og, op, ost = O.batch_play(gid, H, W, grids, players, actions)
+    g, p, st = E.play_batch(gid, H, W, dg, dp, torch.as_tensor(actions, device="cuda"))
+    assert np.array_equal(g.cpu().numpy().reshape(-1, H * W), og) and np.array_equal(p.cpu().numpy(), op)
+    assert np.array_equal(st.cpu().numpy(), ost)
+    over, win, score = E.status_batch(gid, H, W, g, p)
+    oo, ow, osc = O.batch_status(gid, H, W, og, op)
+    assert np.array_equal(over.cpu().numpy(), oo) and np.array_equal(score.cpu().numpy(), osc)
+    assert np.array_equal(win.cpu().numpy()[oo == 1], ow[oo == 1])
+    assert oo.sum() > 1000  # finished games (wins in every direction, full boards) are in the sample
