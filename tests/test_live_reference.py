@@ -24,12 +24,13 @@ def _boards(R, tag):
     if tag.startswith("othello"):
         n = int(tag[-1])
         return R.oth.OthelloBoard(n=n), OthelloBoard(n=n)
-    if tag == "connect4":
-        return R.c4.Connect4Board(width=7, height=6), Connect4Board(width=7, height=6)
+    if tag.startswith("connect4"):
+        w, h = (7, 6) if tag == "connect4" else map(int, tag.split("_")[1].split("x"))
+        return R.c4.Connect4Board(width=w, height=h), Connect4Board(width=w, height=h)
     return R.ttt.TicTacToeBoard(), TicTacToeBoard()
 
 
-@pytest.mark.parametrize("tag", ["othello8", "othello6", "connect4", "tictactoe"])
+@pytest.mark.parametrize("tag", ["othello8", "othello6", "othello4", "connect4", "connect4_5x6", "connect4_8x8", "connect4_4x4", "tictactoe"])
 def test_boards_side_by_side(R, tag):
     rng = np.random.RandomState(7)
     for game in range(12):
@@ -42,7 +43,7 @@ def test_boards_side_by_side(R, tag):
                 assert ref.get_winner() == mine.get_winner()
                 break
             a, b = ref.get_moves(), mine.get_moves()
-            key = (lambda m: int(m)) if tag == "connect4" else (lambda m: (int(m[0]), int(m[1])))
+            key = (lambda m: int(m)) if tag.startswith("connect4") else (lambda m: (int(m[0]), int(m[1])))
             assert sorted(map(key, a)) == sorted(map(key, b))
             other_a, other_b = ref.get_moves(player=-ref.player), mine.get_moves(player=-mine.player)
             assert sorted(map(key, other_a)) == sorted(map(key, other_b))
