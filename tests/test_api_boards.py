@@ -112,3 +112,23 @@ def test_net_mirror_matches_reference_forward(tag):
     assert abs(sum(norm.values()) - 1) < 1e-5 and set(norm) == set(legal)
     pi = net.to_neural_output(norm)
     assert pi.shape == (A,) and abs(pi.sum() - 1) < 1e-5
+
+
+@pytest.mark.parametrize("H,W", [(4, 4), (5, 6), (8, 8), (6, 8)])
+def test_connect4_other_sizes_mirror_equals_oracle(H, W):
+    """closes the loop for non-default Connect4 boards: mirror == reference (tests/test_live_reference.py, where the
+    reference is mounted), HIP == oracle (tests/test_gpu_rules.py), and here mirror == oracle"""
+    from oracle import oracle as O
+    from alphazero_amd.games.connect4 import Connect4Board
+    grids, players, actions = O.random_positions(O.CONNECT4, H, W, 99, 60, 5000)
+    legal = O.batch_legal(O.CONNECT4, H, W, grids, players)
+    og, op, _ = O.batch_play(O.CONNECT4, H, W, grids, players, actions)
+    over, win, score = O.batch_status(O.CONNECT4, H, W, og, op)
+    for i in range(0, len(players), 3):
+        b = Connect4Board(width=W, height=H, grid=grids[i].reshape(H, W).astype(np.float64), player=int(players[i]))
+        assert sorted(int(m) for m in b.get_moves()) == np.flatnonzero(legal[i]).tolist()
+        b.play_move(np.int64(actions[i]))
+        assert np.array_equal(b.grid.astype(np.int8).reshape(-1), og[i]) and b.player == op[i]
+        assert b.is_game_over() == bool(over[i]) and b.get_score() == score[i]
+        if over[i]:
+            assert b.get_winner() == win[i]
