@@ -85,7 +85,7 @@ def test_selfplay_fixture(tag):
     assert eng.stats()["games_done"] == int(fx["episodes"])
 
 
-@pytest.mark.parametrize("tag,n_games,n_sim,slots", [("othello8", 96, 40, 64), ("othello6", 128, 30, 50),
+@pytest.mark.parametrize("tag,n_games,n_sim,slots", [("othello8", 96, 40, 64), ("othello6", 128, 30, 50), ("othello4", 200, 25, 64),
                                                      ("connect4", 160, 50, 64), ("tictactoe", 256, 30, 100)])
 def test_production_mode_equals_oracle_fakenet(tag, n_games, n_sim, slots):
     game, gid, H, W, A, n = TAGS[tag]
