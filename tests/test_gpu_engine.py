@@ -106,6 +106,9 @@ def test_capacity_errors_are_loud():
     eng = E.SelfPlayEngine(0, 8, 8, n_slots=8, n_sim=10, evaluator=E.EVAL_FAKE, sample_capacity=20)
     with pytest.raises(E._lib.AzError, match="sample buffer"):
         eng.run(8)
+    eng = E.SelfPlayEngine(0, 8, 8, n_slots=8, n_sim=10, evaluator=E.EVAL_FAKE, max_plies=12, sample_capacity=4096)
+    with pytest.raises(E._lib.AzError, match="max_plies"):
+        eng.run(8)
 
 
 @pytest.mark.parametrize("tag,n_games,n_sim", [("othello8", 12, 25), ("connect4", 24, 40), ("tictactoe", 64, 25)])
