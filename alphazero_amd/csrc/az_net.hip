@@ -769,34 +769,34 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const float *__restrict__ A, co
 }
 
 // Dense layer for a handful of rows (single-game search, small arenas): one wavefront per (row, 64 output columns),
-// plain fmaf in k order -- the same chain the MFMA tiles compute, so the results are bit-identical -- with 16 weight loads
-// in flight per lane.  The tiled GEMM walks its K tiles serially inside one workgroup (~1 us per tile whatever the
-// row count: 21 / 40 us for fc1 / fc2); this kernel needs 12 / 22 us.
+// plain fmaf in k order -- the same chain the MFMA tiles compute, so the results are bit-identical -- with 16 to 32 weight
+// loads in flight per lane.  The tiled GEMM walks its K tiles serially inside one workgroup (~1 us per tile whatever the
+// row count: 21 / 40 us for fc1 / fc2); this kernel needs 9 / 16 us.
 template <bool RELU>
 __global__ __launch_bounds__(64) void k_dense_small(const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ bias,
                                                     float *__restrict__ Y, int M, int N, int K, const int *__restrict__ dyn_count) {
     if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
     const int m = blockIdx.y, lane = threadIdx.x;
     if (m >= M) return;
-    __shared__ float xs[1024];
-    for (int k = lane; k < K; k += 64) xs[k] = X[(size_t)m * K + k];
-    __syncthreads();
+    const float *x = X + (size_t)m * K;  // wave-uniform: the row's values arrive through scalar loads
     const int n = blockIdx.x * 64 + lane;
     const int nc = n < N ? n : N - 1;
     const float *w = Wt + nc;
     float acc = bias[nc];
-    float cur[16], nxt[16];
+    float wa[16], wb[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) cur[i] = w[(size_t)i * N];
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        if (k0 + 16 < K) {
+    for (int i = 0; i < 16; ++i) wa[i] = w[(size_t)i * N];
+    for (int k0 = 0; k0 < K; k0 += 32) {  // K % 32 == 0; two 16-deep weight buffers in ping-pong (no register moves)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) nxt[i] = w[(size_t)(k0 + 16 + i) * N];
+        for (int i = 0; i < 16; ++i) wb[i] = w[(size_t)(k0 + 16 + i) * N];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = fmaf(x[k0 + i], wa[i], acc);
+        if (k0 + 32 < K) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wa[i] = w[(size_t)(k0 + 32 + i) * N];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc = fmaf(xs[k0 + i], cur[i], acc);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+        for (int i = 0; i < 16; ++i) acc = fmaf(x[k0 + 16 + i], wb[i], acc);
     }
     if (RELU) acc = acc > 0.0f ? acc : 0.0f;
     if (n < N) Y[(size_t)m * N + n] = acc;
@@ -1276,7 +1276,7 @@ static int gemm_go(const float *A, const float *Bw, const float *bias, float *C,
 static int launch_gemm(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
     AZ_REQUIRE(K % 32 == 0, AZ_EINVAL, "GEMM K=%d is not a multiple of 32", K);
     // measured crossover against the tiled GEMM (MI355X): K = 512 up to 128 rows (15 vs 21 us), K = 1024 up to 256 rows (28 vs 40 us)
-    if (M <= (K >= 1024 ? 256 : 128) && K <= 1024 && K % 16 == 0) {  // few rows: latency matters, not throughput
+    if (M <= (K >= 1024 ? 256 : 128) && K % 32 == 0) {  // few rows: latency matters, not throughput
         dim3 grid((unsigned)((N + 63) / 64), (unsigned)M);
         if (relu) hipLaunchKernelGGL((k_dense_small<true>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
         else hipLaunchKernelGGL((k_dense_small<false>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
