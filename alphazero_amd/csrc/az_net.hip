@@ -948,6 +948,59 @@ __global__ __launch_bounds__(256) void k_heads(const float *__restrict__ X, cons
     }
 }
 
+// Heads for a handful of rows: one workgroup per row, one lane per logit (fmaf in k order, as k_dense_small), then the
+// same softmax / tanh arithmetic as k_heads (exact max, az_det_expf, sum in ascending action order).  ~7 us against 15.
+__global__ __launch_bounds__(128) void k_heads_small(const float *__restrict__ X, const float *__restrict__ Wh, const float *__restrict__ bh,
+                                                     int M, int K, int A, int NH, float *__restrict__ probs, float *__restrict__ value,
+                                                     const int *__restrict__ dyn_count) {
+    if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
+    const int m = blockIdx.x, tid = threadIdx.x;
+    if (m >= M) return;
+    __shared__ float lg[128];
+    __shared__ float red[2];
+    const float *x = X + (size_t)m * K;  // wave-uniform
+    const int n = tid < NH ? tid : NH - 1;
+    const float *w = Wh + n;
+    float acc = bh[n];
+    float wa[16], wb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wa[i] = w[(size_t)i * NH];
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wb[i] = w[(size_t)(k0 + 16 + i) * NH];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = fmaf(x[k0 + i], wa[i], acc);
+        if (k0 + 32 < K) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wa[i] = w[(size_t)(k0 + 32 + i) * NH];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = fmaf(x[k0 + 16 + i], wb[i], acc);
+    }
+    lg[tid] = tid < A ? acc : -__builtin_inff();
+    if (tid == A) red[1] = acc;  // value logit
+    __syncthreads();
+    if (tid < 64) {  // the maximum is exact whatever the order
+        float mx = fmaxf(lg[tid], lg[tid + 64]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (tid == 0) red[0] = mx;
+    }
+    __syncthreads();
+    const float mx = red[0];
+    const float e = tid < A ? az_det_expf(acc - mx) : 0.0f;
+    lg[tid] = e;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.0f;
+        for (int a = 0; a < A; ++a) s += lg[a];  // ascending action order
+        red[0] = s;
+        value[m] = az_det_tanhf(red[1]);
+    }
+    __syncthreads();
+    if (tid < A) probs[(size_t)m * A + tid] = e / red[0];
+}
+
 template <int NT>
 constexpr int heads_lds_bytes() { return 4 * (32 * (128 + 2) + 128 * NT * 16 + 32 * (NT * 16 + 1) + 32); }
 
@@ -1314,6 +1367,10 @@ static int heads_go(az_net *n, int B, float *probs, float *value, const int *dyn
 }
 
 static int launch_heads(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
+    if (B <= 128 && n->NH <= 128 && n->F2 % 32 == 0) {  // few rows: latency, not throughput
+        hipLaunchKernelGGL(k_heads_small, dim3((unsigned)B), dim3(128), 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, n->NH, probs, value, dyn);
+        return AZ_OK;
+    }
     switch (n->NH / 16) {
         case 1: return heads_go<1>(n, B, probs, value, dyn, st);
         case 3: return heads_go<3>(n, B, probs, value, dyn, st);
