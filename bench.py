@@ -18,6 +18,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver (before any HIP call)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
