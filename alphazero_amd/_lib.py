@@ -28,13 +28,13 @@ class EngineCfg(C.Structure):
 class EngineStats(C.Structure):
     _fields_ = [("games_done", C.c_int64), ("samples", C.c_int64), ("net_evals", C.c_int64),
                 ("lockstep_iters", C.c_int64), ("plies", C.c_int64), ("max_nodes_used", C.c_int32),
-                ("error_flags", C.c_int32), ("graph_replays", C.c_int64)]
+                ("error_flags", C.c_int32), ("graph_replays", C.c_int64), ("max_path_len", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/az_amd.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "az_last_error", "az_version", "az_board_legal_batch", "az_board_play_batch", "az_board_status_batch",
-    "az_net_create", "az_net_destroy", "az_net_set_tensor", "az_net_commit", "az_net_forward", "az_net_forward_dyn",
+    "az_net_create", "az_net_destroy", "az_net_set_tensor", "az_net_commit", "az_net_set_tensor_device", "az_net_commit_device", "az_net_forward", "az_net_forward_dyn",
     "az_net_action_size",
     "az_net_flops_per_board", "az_net_time_stage", "az_net_profile", "az_net_profiling", "az_net_profile_read", "az_engine_create", "az_engine_destroy", "az_engine_run",
     "az_engine_get_stats", "az_engine_samples", "az_engine_set_roots", "az_engine_search", "az_engine_advance",
@@ -61,6 +61,8 @@ def lib():
     L.az_net_destroy.restype = None
     L.az_net_set_tensor.argtypes = [vp, C.c_char_p, vp, i64]
     L.az_net_commit.argtypes = [vp, vp]
+    L.az_net_set_tensor_device.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    L.az_net_commit_device.argtypes = [vp, vp]
     L.az_net_forward.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.az_net_forward_dyn.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
     L.az_net_action_size.argtypes = [vp]

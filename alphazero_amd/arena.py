@@ -85,18 +85,54 @@ class BatchedArena:
                               evaluator=EVAL_ROLLOUT if rollout else EVAL_NET, dirichlet_alpha=None, dirichlet_epsilon=None, temp_max_step=-1, temp_min_step=0,
                               tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed, max_plies=plies, sample_capacity=16)
 
-    def play_games(self, n_rounds, start_player=None, return_stats=True):
+    def play_games(self, n_rounds, start_player=None, return_stats=True, shard=True, record_moves=False):
+        """all rounds at once.  Inside a torch.distributed job (one process per GPU) the rounds are sharded over the
+        ranks in contiguous blocks and the per-game results (winner, score: a few bytes per game) are all-gathered, so
+        every rank returns the stats of ALL rounds (optional collective 3).  Game ids are the global round
+        numbers: the games do not depend on the number of ranks.  record_moves keeps the move vector of every ply in
+        self.moves (tests)."""
         import numpy as np
+        import torch
         from collections import defaultdict
-        G = n_rounds
-        p2_starts = np.array([{1: False, 2: True}.get(start_player, bool(r % 2)) for r in range(G)])
-        side1 = np.where(p2_starts, -1, 1).astype(np.int8)  # colour +1 moves first
+        from .dist import all_gather_rows, initialized, rank_world
+        rank, world = rank_world() if shard else (0, 1)
+        per = (n_rounds + world - 1) // world
+        lo = min(n_rounds, rank * per)
+        G = min(per, n_rounds - lo)
+        p2_all = np.array([{1: False, 2: True}.get(start_player, bool(r % 2)) for r in range(n_rounds)])
+        side_all = np.where(p2_all, -1, 1).astype(np.int8)  # colour +1 moves first
+        res = np.full((per, 2), -2, np.int32)  # (winner, score) of this rank's rounds, padded to `per` rows
+        self.moves = []
+        if G > 0:
+            winner, score = self._play(G, side_all[lo:lo + G], np.arange(lo, lo + G, dtype=np.uint32), record_moves)
+            res[:G, 0], res[:G, 1] = winner, score
+        if shard and initialized():  # also with one rank: the collective is part of the path
+            dev = "cuda" if torch.distributed.get_backend() != "gloo" else "cpu"
+            res_all = all_gather_rows(torch.from_numpy(res).to(dev), force=True).cpu().numpy().reshape(world, per, 2)
+            res = np.concatenate([res_all[r, :min(per, max(0, n_rounds - r * per))] for r in range(world)])
+        winner, score = res[:n_rounds, 0], res[:n_rounds, 1]
+        stats = {"player1": [], "player2": [], "draw": 0, "player1_starts": defaultdict(int), "player2_starts": defaultdict(int)}
+        for g in range(n_rounds):
+            starter = f"player{2 if p2_all[g] else 1}_starts"
+            if winner[g] == 0:
+                stats["draw"] += 1
+                stats[starter]["draw"] += 1
+            else:
+                who = 1 if winner[g] == side_all[g] else 2
+                sc = int(abs(score[g]))
+                stats[f"player{who}"].append(float("inf") if self.gid == 2 and sc == 32767 else sc)  # tictactoe.py:119-126
+                stats[starter]["win" if who == (2 if p2_all[g] else 1) else "loss"] += 1
+        return stats if return_stats else None
+
+    def _play(self, G, side1, round_ids, record_moves=False):
+        """G games in lock-step on this GPU; returns (winner, score) per game"""
+        import numpy as np
         board = {0: lambda: __import__("alphazero_amd.games.othello", fromlist=["OthelloBoard"]).OthelloBoard(n=self.H),
                  1: lambda: __import__("alphazero_amd.games.connect4", fromlist=["Connect4Board"]).Connect4Board(width=self.W, height=self.H),
                  2: lambda: __import__("alphazero_amd.games.tictactoe", fromlist=["TicTacToeBoard"]).TicTacToeBoard()}[self.gid]()
         grids = np.tile(board.grid.astype(np.int8)[None], (G, 1, 1))
         ones = np.ones(G, np.int8)
-        ids = np.arange(G, dtype=np.uint32) + np.uint32(self.seed * 100003)
+        ids = round_ids.astype(np.uint32) + np.uint32(self.seed * 100003)
         e1 = self._engine(self.nn, G, self.n_sim, self.seed)
         e1.set_roots(grids, ones, game_ids=ids)
         e1.set_sides(side1)
@@ -117,22 +153,14 @@ class BatchedArena:
             else:
                 b = e1.baseline_moves(self.opponent, seed=self.seed + 7)
             moves = np.where(a >= 0, a, b).astype(np.int32)
+            if record_moves:
+                self.moves.append(moves.copy())
             e1.play(moves)
             if e2 is not None:
                 e2.play(moves)
         else:
             raise RuntimeError("arena games did not finish")
-        stats = {"player1": [], "player2": [], "draw": 0, "player1_starts": defaultdict(int), "player2_starts": defaultdict(int)}
-        for g in range(G):
-            starter = f"player{2 if p2_starts[g] else 1}_starts"
-            if winner[g] == 0:
-                stats["draw"] += 1
-                stats[starter]["draw"] += 1
-            else:
-                who = 1 if winner[g] == side1[g] else 2
-                stats[f"player{who}"].append(int(abs(score[g])))
-                stats[starter]["win" if who == (2 if p2_starts[g] else 1) else "loss"] += 1
         e1.close()
         if e2 is not None:
             e2.close()
-        return stats if return_stats else None
+        return winner, score

@@ -11,4 +11,4 @@ void az_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *az_last_error(void) { return g_err; }
-extern "C" int az_version(void) { return 100; }
+extern "C" int az_version(void) { return 101; }

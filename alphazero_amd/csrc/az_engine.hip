@@ -45,6 +45,7 @@
 #define ERR_SAMPLE_CAP 2
 #define ERR_PLY_CAP 4
 #define ERR_INTERNAL 8
+#define ERR_RNG 16  // the Gamma rejection sampler of the root noise gave up (p < 1e-38 per draw): reported, never papered over
 
 #define LPG 16          // lanes per game
 #define GPB (256 / LPG) // games per 256-thread block
@@ -83,6 +84,7 @@ struct EngDev {
     int8_t *o_state; float *o_pi; int8_t *o_z; int *o_meta, *o_visits;
     unsigned long long *ctr;
     int *err, *max_nodes;
+    int *max_path;  // longest root..leaf path (nodes) of any simulation, recorded only beyond LPG (the parent-chasing backup)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -235,6 +237,7 @@ AZ_D int pick_child_grp(const EngDev &E, int g, const Node *pool, const Node &pa
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { mask[r] = grp_ballot(key[r] == best); cnt += __popc(mask[r]); }
+    if (cnt == 0 && sub == 0) atomicOr(E.err, ERR_INTERNAL);  // NaN scores (a diverged network): no key equals the maximum
     int k = 0;
     if (E.tie_mode == AZ_TIE_RANDOM && cnt > 1) {  // with a single maximum the draw cannot change the result
         Philox4 rr = az_philox(E.seed, E.game_id[g], (u32)ply, (u32)sim + E.sim_base, AZ_P_TIE_SELECT, (u32)depth);
@@ -264,6 +267,7 @@ AZ_D int pick_child_grp(const EngDev &E, int g, const Node *pool, const Node &pa
 
 AZ_D double log_gamma_draw(const EngDev &E, u32 gid, int ply, int sim, double alpha, u32 j) {
     double d = (alpha + 1.0) - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d), g = d;
+    bool accepted = false;
     for (u32 att = 0; att < 64; ++att) {
         Philox4 r = az_philox(E.seed, gid, (u32)ply, (u32)sim, AZ_P_NOISE_NORMAL, j | (att << 8));
         Philox4 q = az_philox(E.seed, gid, (u32)ply, (u32)sim, AZ_P_NOISE_NORMAL, j | (att << 8) | 0x80000000u);
@@ -275,8 +279,9 @@ AZ_D double log_gamma_draw(const EngDev &E, u32 gid, int ply, int sim, double al
         if (!(v > 0.0)) continue;
         v = v * v * v;
         double u = 1.0 - az_u53(q.x, q.y);
-        if (az_det_log(u) < 0.5 * x * x + d - d * v + d * az_det_log(v)) { g = d * v; break; }
+        if (az_det_log(u) < 0.5 * x * x + d - d * v + d * az_det_log(v)) { g = d * v; accepted = true; break; }
     }
+    if (!accepted) atomicOr(E.err, ERR_RNG);
     Philox4 r = az_philox(E.seed, gid, (u32)ply, (u32)sim, AZ_P_NOISE_BOOST, j);
     double ub = 1.0 - az_u53(r.x, r.y);
     return az_det_log(g) + az_det_log(ub) / alpha;
@@ -382,7 +387,7 @@ __global__ void k_reset_all(EngDev E, u32 first_id, int n_games) {
         E.ctr[CTR_NEXT_GAME] = (unsigned long long)(n_games < E.G ? n_games : E.G);
         E.ctr[CTR_TOTAL_GAMES] = (unsigned long long)n_games;
         E.ctr[CTR_FIRST_ID] = first_id;
-        *E.err = 0; *E.max_nodes = 0;
+        *E.err = 0; *E.max_nodes = 0; *E.max_path = 0;
         E.batch_cnt[0] = E.batch_cnt[1] = E.batch_cnt[2] = 0;
     }
     if (g >= E.G) return;
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
         }
         PSTAMP(5)
         E.path[(size_t)g * LPG + sub] = my_path;
-        if (sub == 0) E.path_len[g] = plen;
+        if (sub == 0) { E.path_len[g] = plen; if (plen > LPG) atomicMax(E.max_path, plen); }
         if (bad) { if (sub == 0) atomicOr(E.err, ERR_INTERNAL); }
         else if (cur.flags & F_TERMINAL) { status = LS_TERM; w = cur.win; }
         else if (az_status_grp(E.gd, b, &w, sub)) {  // mcts.py:185-186
@@ -710,6 +715,7 @@ __global__ __launch_bounds__(256) void k_rollout_step(EngDev E, int sim) {
     if (fabs(outcome) < 1e-4) reward = 0.0;
     else reward = ((double)player_to_play * outcome > 0.0) ? -fabs(outcome) : fabs(outcome);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (plen > LPG && sub == 0) atomicMax(E.max_path, plen);
     if (plen <= LPG) {
         if (sub < plen) {
             Node n = load_node(pool + my_path);
@@ -937,6 +943,17 @@ __global__ void k_best_moves(EngDev E, int *actions) {
     actions[g] = pool[fc + pick].act;
 }
 
+// TicTacToeBoard.get_score (tictactoe.py:119-126) is +inf when the side to move holds two cells of an alignment whose
+// third cell is free, else 0
+AZ_D bool ttt_can_win_at_once(const BB &b) {
+    const u64 own = b.player > 0 ? b.p1 : b.m1, occ = b.p1 | b.m1;
+    const u64 L[8] = {0x7ULL, 0x7ULL << 8, 0x7ULL << 16, 0x010101ULL, 0x010101ULL << 1, 0x010101ULL << 2,
+                      (1ULL | (1ULL << 9) | (1ULL << 18)), ((1ULL << 2) | (1ULL << 9) | (1ULL << 16))};
+    bool threat = false;
+    for (int l = 0; l < 8; ++l) threat |= (__popcll(own & L[l]) == 2 && __popcll(occ & L[l]) == 2);
+    return threat;
+}
+
 // RandomPlayer / GreedyPlayer (players.py:76-123) for the slots where the OTHER colour is to move:
 // kind 0 = uniform legal move, kind 1 = best immediate -get_score() of the position after the move, ties uniform.
 __global__ void k_baseline_moves(EngDev E, int kind, u32 seed, int *actions) {
@@ -960,12 +977,7 @@ __global__ void k_baseline_moves(EngDev E, int kind, u32 seed, int *actions) {
             az_play(gd, c, az_bit_to_action(gd, bit));
             int sc;
             if (gd.game == AZ_TICTACTOE) {  // -get_score(): -inf when the opponent can complete a line at once (tictactoe.py:119-126)
-                u64 opp = c.player > 0 ? c.p1 : c.m1, occ = c.p1 | c.m1;
-                bool threat = false;
-                const u64 L[8] = {0x7ULL, 0x7ULL << 8, 0x7ULL << 16, 0x010101ULL, 0x010101ULL << 1, 0x010101ULL << 2,
-                                  (1ULL | (1ULL << 9) | (1ULL << 18)), ((1ULL << 2) | (1ULL << 9) | (1ULL << 16))};
-                for (int l = 0; l < 8; ++l) threat |= (__popcll(opp & L[l]) == 2 && __popcll(occ & L[l]) == 2);
-                sc = threat ? -1 : 0;
+                sc = ttt_can_win_at_once(c) ? -1 : 0;
             } else {
                 sc = -(c.player * (__popcll(c.p1) - __popcll(c.m1)));  // -sum(player*grid) after the move
             }
@@ -986,7 +998,8 @@ __global__ void k_root_status(EngDev E, int8_t *players, uint8_t *over, int8_t *
     int w = 2;
     bool o = az_status(E.gd, b, &w);
     players[g] = (int8_t)b.player; over[g] = o ? 1 : 0; winner[g] = (int8_t)(o ? w : 2);
-    score[g] = b.player * (__popcll(b.p1) - __popcll(b.m1));
+    // Board.get_score from the side to move's viewpoint; TicTacToe's +inf is reported as 32767
+    score[g] = E.gd.game == AZ_TICTACTOE ? (ttt_can_win_at_once(b) ? 32767 : 0) : b.player * (__popcll(b.p1) - __popcll(b.m1));
 }
 
 // closed-form fake network (tests): reads the canonical board back from nn_in
@@ -1020,7 +1033,7 @@ struct az_engine {
     hipStream_t stream;
     std::vector<void *> allocs;
     unsigned long long *h_ctr;  // pinned
-    int *h_err;                 // pinned [2] : err, max_nodes
+    int *h_err;                 // pinned [3] : err, max_nodes, max_path
     long long lockstep_iters;
     u32 sim_base = 0;
     // The engine runs on a stream of its own (graph capture is not allowed on the legacy default stream); every entry
@@ -1111,13 +1124,13 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
     A_(nn_in, G * gd.cells); A_(probs, G * gd.A); A_(value, G); A_(row_of_slot, G); A_(evals, G); A_(batch_cnt, 4);
     A_(samp_idx, G * (size_t)d.max_plies);
     A_(o_state, S * gd.cells); A_(o_pi, S * gd.A); A_(o_z, S); A_(o_meta, S * 4); A_(o_visits, S * gd.A);
-    A_(ctr, CTR_COUNT); A_(err, 1); A_(max_nodes, 1);
+    A_(ctr, CTR_COUNT); A_(err, 1); A_(max_nodes, 1); A_(max_path, 1);
 #undef A_
     if (rc == AZ_OK) rc = dev_alloc(e, &e->scr_a, G);
     if (rc == AZ_OK) rc = dev_alloc(e, &e->scr_b, G);
     if (rc == AZ_OK) rc = dev_alloc(e, &e->scr_c, 3 * G);
     if (rc == AZ_OK && hipHostMalloc((void **)&e->h_ctr, sizeof(unsigned long long) * CTR_COUNT) != hipSuccess) rc = AZ_EHIP;
-    if (rc == AZ_OK && hipHostMalloc((void **)&e->h_err, sizeof(int) * 2) != hipSuccess) rc = AZ_EHIP;
+    if (rc == AZ_OK && hipHostMalloc((void **)&e->h_err, sizeof(int) * 3) != hipSuccess) rc = AZ_EHIP;
     if (rc != AZ_OK) { az_engine_destroy(e); return rc; }
     if (hipStreamSynchronize(e->stream) != hipSuccess) { az_engine_destroy(e); az_set_error("stream sync failed"); return AZ_EHIP; }
     *out = e;
@@ -1222,6 +1235,7 @@ static int fetch_counters(az_engine *e) {
     AZ_HIP(hipMemcpyAsync(e->h_ctr, e->d.ctr, sizeof(unsigned long long) * CTR_COUNT, hipMemcpyDeviceToHost, e->stream));
     AZ_HIP(hipMemcpyAsync(&e->h_err[0], e->d.err, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     AZ_HIP(hipMemcpyAsync(&e->h_err[1], e->d.max_nodes, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    AZ_HIP(hipMemcpyAsync(&e->h_err[2], e->d.max_path, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     AZ_HIP(hipStreamSynchronize(e->stream));
     return AZ_OK;
 }
@@ -1231,7 +1245,8 @@ static int check_err(az_engine *e) {
     if (f & ERR_NODE_POOL) { az_set_error("tree node pool exhausted (node_capacity=%d)", e->cfg.node_capacity); return AZ_ECAPACITY; }
     if (f & ERR_SAMPLE_CAP) { az_set_error("sample buffer exhausted (sample_capacity=%lld)", (long long)e->cfg.sample_capacity); return AZ_ECAPACITY; }
     if (f & ERR_PLY_CAP) { az_set_error("game longer than max_plies=%d", e->cfg.max_plies); return AZ_ECAPACITY; }
-    if (f & ERR_INTERNAL) { az_set_error("internal tree invariant violated"); return AZ_ESTATE; }
+    if (f & ERR_RNG) { az_set_error("Dirichlet noise: the Gamma rejection sampler did not accept within 64 attempts"); return AZ_ESTATE; }
+    if (f & ERR_INTERNAL) { az_set_error("internal tree invariant violated (no selectable child: NaN priors or values?)"); return AZ_ESTATE; }
     return AZ_OK;
 }
 
@@ -1273,6 +1288,8 @@ extern "C" int az_engine_get_stats(az_engine *e, az_engine_stats *out) {
     out->max_nodes_used = e->h_err[1];
     out->error_flags = e->h_err[0];
     out->graph_replays = e->graph_replays;
+    out->max_path_len = e->h_err[2];
+    out->reserved = 0;
     return AZ_OK;
 }
 

@@ -1006,7 +1006,10 @@ constexpr int heads_lds_bytes() { return 4 * (32 * (128 + 2) + 128 * NT * 16 + 3
 
 struct MlpParams { float f1w[81], f1b[9], f2w[81], f2b[9], hw[90], hb[10]; };
 
-__global__ void k_mlp(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, MlpParams p, float *__restrict__ probs, float *__restrict__ value) {
+// The parameters live in device memory behind a pointer that never changes (as the conv nets' weights do): a captured
+// HIP graph of the search replays this launch with the weights az_net_commit uploaded last, not the ones at capture.
+__global__ void k_mlp(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, const MlpParams *__restrict__ pp, float *__restrict__ probs, float *__restrict__ value) {
+    const MlpParams &p = *pp;
     if (dyn_count) { int c = *dyn_count; B = c < B ? c : B; }
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -1029,11 +1032,13 @@ __global__ void k_mlp(const float *__restrict__ in, int B, const int *__restrict
 struct az_net {
     int game, H, W, CH, CW, A, F1, F2, FIN, NH, max_batch;
     std::map<std::string, std::vector<float>> raw;
+    std::map<std::string, std::pair<float *, size_t>> raw_dev;  // state_dict tensors handed over in device memory (az_net_set_tensor_device)
     std::vector<void *> allocs;
     TrunkParams tp;
     float *fc1w, *fc1b, *fc2w, *fc2b, *hw, *hb;
     float *feat, *h1, *h2;
-    MlpParams mlp;
+    MlpParams mlp;           // host staging of the TicTacToe MLP
+    MlpParams *mlp_dev = nullptr;  // what k_mlp reads
     bool committed;
     // live per-stage timing (az_net_profile): HIP events around every stage launch, harvested in batches
     bool prof = false;
@@ -1082,6 +1087,10 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
         NA(n->feat, (size_t)max_batch * n->FIN) NA(n->h1, (size_t)max_batch * n->F1) NA(n->h2, (size_t)max_batch * n->F2)
 #undef NA
         if (rc != AZ_OK) { az_net_destroy(n); return rc; }
+    } else {
+        float *p = nullptr;
+        if (net_alloc(n, &p, (sizeof(MlpParams) + sizeof(float) - 1) / sizeof(float)) != AZ_OK) { az_net_destroy(n); return AZ_EHIP; }
+        n->mlp_dev = reinterpret_cast<MlpParams *>(p);
     }
     *out = n;
     return AZ_OK;
@@ -1167,6 +1176,8 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
         for (int a = 0; a < 9; ++a) { n->mlp.hb[a] = (*pb)[a]; for (int k = 0; k < 9; ++k) n->mlp.hw[k * 10 + a] = (*pw)[a * 9 + k]; }
         n->mlp.hb[9] = (*vb)[0];
         for (int k = 0; k < 9; ++k) n->mlp.hw[k * 10 + 9] = (*vw)[k];
+        AZ_HIP(hipMemcpyAsync(n->mlp_dev, &n->mlp, sizeof(MlpParams), hipMemcpyHostToDevice, st));
+        AZ_HIP(hipStreamSynchronize(st));
         n->committed = true;
         return AZ_OK;
     }
@@ -1249,6 +1260,145 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
         for (int k = 0; k < n->F2; ++k) fw[(size_t)k * n->NH + n->A] = (*vw)[k];
         AZ_TRY(upload(n->hw, fw, st)); AZ_TRY(upload(n->hb, fb, st));
     }
+    n->committed = true;
+    return AZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same fold + re-tiling on the device (weight hand-off after optimize_network without a host round trip,
+// trainer.py:383-387): one thread per destination element, float64 arithmetic in the host code's operation order
+// (no contraction), so both paths produce identical bits.
+// ---------------------------------------------------------------------------------------------
+enum { FOLD_BIAS = 0, FOLD_W1F, FOLD_W1P, FOLD_WP, FOLD_WQ, FOLD_DENSE_T, FOLD_HEADS_W, FOLD_HEADS_B };
+struct FoldJob {
+    int mode, n_dst, K, N, A;
+    const float *w, *b, *g, *beta, *mean, *var;  // w: the layer's weight (heads: fc_probs.weight), b: bias (heads: fc_value.*)
+    float *dst;
+};
+AZ_D double fold_scale(const FoldJob &j, int c) { return (double)j.g[c] / sqrt((double)j.var[c] + BN_EPS); }
+
+__global__ void k_fold(FoldJob j) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= j.n_dst) return;
+    float out = 0.0f;
+    switch (j.mode) {
+        case FOLD_BIAS: out = (float)(((double)j.b[i] - (double)j.mean[i]) * fold_scale(j, i) + (double)j.beta[i]); break;
+        case FOLD_W1F: {  // [k-step s][nt][lane] = W'[oc = nt*16 + (lane&15)][tap = 4s + (lane>>4)], 0 for tap >= 9
+            const int lane = i % 64, nt = (i / 64) % 2, sidx = i / 128;
+            const int oc = nt * 16 + (lane & 15), t = 4 * sidx + (lane >> 4);
+            if (t < 9) out = (float)((double)j.w[oc * 9 + t] * fold_scale(j, oc));
+            break;
+        }
+        case FOLD_W1P: {  // [k-step s][lane] = W'[oc = lane&31][tap = 2s + (lane>>5)], 0 for tap 9
+            const int lane = i % 64, sidx = i / 64;
+            const int oc = lane & 31, t = 2 * sidx + (lane >> 5);
+            if (t < 9) out = (float)((double)j.w[oc * 9 + t] * fold_scale(j, oc));
+            break;
+        }
+        case FOLD_WP: {  // [tap][jj / 4][lane][jj % 4] = W'[oc = lane&31][ic = 2 jj + (lane>>5)][tap]
+            const int r = i % 4, lane = (i / 4) % 64, q = (i / 256) % 4, t = i / 1024;
+            const int jj = 4 * q + r, oc = lane & 31, ic = 2 * jj + (lane >> 5);
+            out = (float)((double)j.w[(oc * NCH + ic) * 9 + t] * fold_scale(j, oc));
+            break;
+        }
+        case FOLD_WQ: {  // fragment f = 2 j8 + nt at [tap][f / 4][lane][f % 4] = W'[oc = nt*16 + (lane&15)][ic = 4 j8 + (lane>>4)][tap]
+            const int r = i % 4, lane = (i / 4) % 64, q = (i / 256) % 4, t = i / 1024;
+            const int f = 4 * q + r, j8 = f / 2, nt = f % 2, oc = nt * 16 + (lane & 15), ic = 4 * j8 + (lane >> 4);
+            out = (float)((double)j.w[(oc * NCH + ic) * 9 + t] * fold_scale(j, oc));
+            break;
+        }
+        case FOLD_DENSE_T: {  // dst[k][n] = W[n][k] * s[n]
+            const int n = i % j.N, k = i / j.N;
+            out = (float)((double)j.w[(size_t)n * j.K + k] * fold_scale(j, n));
+            break;
+        }
+        case FOLD_HEADS_W: {  // dst[k][a] = fc_probs.weight[a][k] | fc_value.weight[k] | 0   (row width N)
+            const int a = i % j.N, k = i / j.N;
+            out = a < j.A ? j.w[(size_t)a * j.K + k] : (a == j.A ? j.b[k] : 0.0f);
+            break;
+        }
+        default: {  // FOLD_HEADS_B: dst[a] = fc_probs.bias[a] | fc_value.bias | 0
+            out = i < j.A ? j.w[i] : (i == j.A ? j.b[0] : 0.0f);
+            break;
+        }
+    }
+    j.dst[i] = out;
+}
+
+extern "C" int az_net_set_tensor_device(az_net *n, const char *name, const float *d_data, int64_t numel, void *stream) {
+    AZ_REQUIRE(n && name && d_data && numel > 0, AZ_EINVAL, "bad arguments");
+    auto it = n->raw_dev.find(name);
+    if (it == n->raw_dev.end() || it->second.second != (size_t)numel) {
+        float *p = nullptr;
+        AZ_TRY(net_alloc(n, &p, (size_t)numel));  // a replaced buffer stays in `allocs` until az_net_destroy (shapes never change in practice)
+        n->raw_dev[name] = std::make_pair(p, (size_t)numel);
+        it = n->raw_dev.find(name);
+    }
+    AZ_HIP(hipMemcpyAsync(it->second.first, d_data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    n->committed = false;
+    return AZ_OK;
+}
+
+static int need_dev(az_net *n, const std::string &k, size_t numel, const float **out) {
+    auto it = n->raw_dev.find(k);
+    AZ_REQUIRE(it != n->raw_dev.end(), AZ_ESTATE, "missing device tensor '%s'", k.c_str());
+    AZ_REQUIRE(it->second.second == numel, AZ_EINVAL, "tensor '%s' has %zu elements, expected %zu", k.c_str(), it->second.second, numel);
+    *out = it->second.first;
+    return AZ_OK;
+}
+
+static int fold_launch(az_net *n, int mode, float *dst, int n_dst, const std::string &wname, size_t wn, const std::string &bname, size_t bn,
+                       const std::string &bnname, int C, int K, int N, int A, hipStream_t st) {
+    FoldJob j;
+    memset(&j, 0, sizeof j);
+    j.mode = mode; j.n_dst = n_dst; j.K = K; j.N = N; j.A = A; j.dst = dst;
+    if (!wname.empty()) AZ_TRY(need_dev(n, wname, wn, &j.w));
+    if (!bname.empty()) AZ_TRY(need_dev(n, bname, bn, &j.b));
+    if (!bnname.empty()) {
+        AZ_TRY(need_dev(n, bnname + ".weight", C, &j.g)); AZ_TRY(need_dev(n, bnname + ".bias", C, &j.beta));
+        AZ_TRY(need_dev(n, bnname + ".running_mean", C, &j.mean)); AZ_TRY(need_dev(n, bnname + ".running_var", C, &j.var));
+    }
+    hipLaunchKernelGGL(k_fold, dim3((unsigned)((n_dst + 255) / 256)), dim3(256), 0, st, j);
+    return AZ_OK;
+}
+
+// az_net_commit for tensors set with az_net_set_tensor_device: nothing touches the host
+extern "C" int az_net_commit_device(az_net *n, void *stream) {
+    AZ_REQUIRE(n, AZ_EINVAL, "null net");
+    hipStream_t st = (hipStream_t)stream;
+    if (n->game == AZ_TICTACTOE) {
+        MlpParams *m = n->mlp_dev;
+        AZ_TRY(fold_launch(n, FOLD_DENSE_T, m->f1w, 81, "fc1.weight", 81, "", 0, "bn1", 9, 9, 9, 0, st));
+        AZ_TRY(fold_launch(n, FOLD_BIAS, m->f1b, 9, "", 0, "fc1.bias", 9, "bn1", 9, 0, 0, 0, st));
+        AZ_TRY(fold_launch(n, FOLD_DENSE_T, m->f2w, 81, "fc2.weight", 81, "", 0, "bn2", 9, 9, 9, 0, st));
+        AZ_TRY(fold_launch(n, FOLD_BIAS, m->f2b, 9, "", 0, "fc2.bias", 9, "bn2", 9, 0, 0, 0, st));
+        AZ_TRY(fold_launch(n, FOLD_HEADS_W, m->hw, 90, "fc_probs.weight", 81, "fc_value.weight", 9, "", 0, 9, 10, 9, st));
+        AZ_TRY(fold_launch(n, FOLD_HEADS_B, m->hb, 10, "fc_probs.bias", 9, "fc_value.bias", 1, "", 0, 0, 10, 9, st));
+        AZ_HIP(hipGetLastError());
+        n->committed = true;
+        return AZ_OK;
+    }
+    for (int l = 0; l < 4; ++l) {
+        const int IC = l == 0 ? 1 : NCH;
+        const std::string cn = "conv" + std::to_string(l + 1), bnn = "bn" + std::to_string(l + 1);
+        const size_t wn = (size_t)NCH * IC * 9;
+        if (l == 0) {
+            AZ_TRY(fold_launch(n, FOLD_BIAS, (float *)n->tp.b1, NCH, "", 0, cn + ".bias", NCH, bnn, NCH, 0, 0, 0, st));
+            AZ_TRY(fold_launch(n, FOLD_W1F, (float *)n->tp.w1f, 3 * 2 * 64, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
+            AZ_TRY(fold_launch(n, FOLD_W1P, (float *)n->tp.w1p, 5 * 64, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
+        } else {
+            AZ_TRY(fold_launch(n, FOLD_BIAS, (float *)n->tp.cb[l - 1], NCH, "", 0, cn + ".bias", NCH, bnn, NCH, 0, 0, 0, st));
+            AZ_TRY(fold_launch(n, FOLD_WP, (float *)n->tp.wp[l - 1], 9 * 16 * 64, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
+            AZ_TRY(fold_launch(n, FOLD_WQ, (float *)n->tp.wq[l - 1], 9 * 16 * 64, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
+        }
+    }
+    AZ_TRY(fold_launch(n, FOLD_DENSE_T, n->fc1w, n->FIN * n->F1, "fc1.weight", (size_t)n->F1 * n->FIN, "", 0, "fc_bn1", n->F1, n->FIN, n->F1, 0, st));
+    AZ_TRY(fold_launch(n, FOLD_BIAS, n->fc1b, n->F1, "", 0, "fc1.bias", n->F1, "fc_bn1", n->F1, 0, 0, 0, st));
+    AZ_TRY(fold_launch(n, FOLD_DENSE_T, n->fc2w, n->F1 * n->F2, "fc2.weight", (size_t)n->F2 * n->F1, "", 0, "fc_bn2", n->F2, n->F1, n->F2, 0, st));
+    AZ_TRY(fold_launch(n, FOLD_BIAS, n->fc2b, n->F2, "", 0, "fc2.bias", n->F2, "fc_bn2", n->F2, 0, 0, 0, st));
+    AZ_TRY(fold_launch(n, FOLD_HEADS_W, n->hw, n->F2 * n->NH, "fc_probs.weight", (size_t)n->A * n->F2, "fc_value.weight", n->F2, "", 0, n->F2, n->NH, n->A, st));
+    AZ_TRY(fold_launch(n, FOLD_HEADS_B, n->hb, n->NH, "fc_probs.bias", n->A, "fc_value.bias", 1, "", 0, 0, n->NH, n->A, st));
+    AZ_HIP(hipGetLastError());
     n->committed = true;
     return AZ_OK;
 }
@@ -1436,7 +1586,7 @@ static int forward_impl(az_net *n, const float *d_input, int B, const int *dyn, 
     AZ_REQUIRE(B > 0 && B <= n->max_batch, AZ_EINVAL, "batch %d outside (0, max_batch=%d]", B, n->max_batch);
     hipStream_t st = (hipStream_t)stream;
     if (n->game == AZ_TICTACTOE) {
-        hipLaunchKernelGGL(k_mlp, dim3((B + 63) / 64), dim3(64), 0, st, d_input, B, dyn, n->mlp, d_probs, d_value);
+        hipLaunchKernelGGL(k_mlp, dim3((B + 63) / 64), dim3(64), 0, st, d_input, B, dyn, n->mlp_dev, d_probs, d_value);
         return AZ_OK;
     }
     if (!n->prof) {

@@ -112,9 +112,18 @@ class HipNet:
         self.load_state_dict(state_dict)
 
     def load_state_dict(self, state_dict):
-        for k, v in state_dict.items():
-            if k.endswith("num_batches_tracked"):
-                continue
+        """weights in (update_network, trainer.py:383-387).  CUDA tensors never leave the device: BatchNorm is folded and
+        the weights are re-tiled by device kernels (az_net_commit_device); host tensors / numpy arrays take the host fold."""
+        items = [(k, v) for k, v in state_dict.items() if not k.endswith("num_batches_tracked")]
+        if items and all(isinstance(v, torch.Tensor) and v.is_cuda for _, v in items):
+            keep = []
+            for k, v in items:
+                t = v.detach().to(torch.float32).contiguous()
+                keep.append(t)  # alive until the copies have been queued on this stream
+                check(lib().az_net_set_tensor_device(self.h, k.encode(), t.data_ptr(), t.numel(), _stream_ptr()))
+            check(lib().az_net_commit_device(self.h, _stream_ptr()))
+            return
+        for k, v in items:
             a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             a = np.ascontiguousarray(a, dtype=np.float32)
             check(lib().az_net_set_tensor(self.h, k.encode(), a.ctypes.data, a.size))

@@ -50,6 +50,7 @@ class MCT:
             raise ValueError(f"A neural network has been set for the MCT but the evaluation method is {self.eval_method}")
         self._seed = int(np.random.randint(0, 2**31 - 1)) if seed is None else int(seed)
         self._engine = None           # device tree (one engine slot)
+        self._pool_sims = 0           # simulations per search the slot's node pools were sized for (0: compute_time mode)
         self._hipnet = None
         self._root_key = None         # (grid bytes, player) of the position the device root stands for
         self._last_board = None
@@ -66,6 +67,7 @@ class MCT:
         self._nn = nn
         self._hipnet = None
         self._engine = None
+        self._pool_sims = 0
         self._root_key = None
 
     def get_stats(self):
@@ -76,7 +78,7 @@ class MCT:
         start = time()
         if n_sim is None and compute_time is None:
             raise ValueError("MCT.search needs to have either n_sim or compute_time specified.")
-        self._sync_device_root(board)
+        self._sync_device_root(board, n_sim)
         if n_sim is not None:
             self._engine.search(n_sim)
             self.n_rollouts = n_sim
@@ -120,12 +122,15 @@ class MCT:
             return [], [], [], [], 0
         return self._engine.root_children(0)
 
-    def _sync_device_root(self, board):
+    def _sync_device_root(self, board, n_sim=None):
         from .engine import EVAL_NET, EVAL_ROLLOUT, NOISE_OFF, NOISE_PHILOX, TIE_RANDOM, SelfPlayEngine
         neural = self.eval_method == TreeEval.NEURAL
         if neural and self._nn is None:
             raise ValueError("The MCT has no neural network to evaluate positions with.")
         H, W = board.grid.shape
+        if self._engine is not None and n_sim is not None and self._pool_sims and n_sim > self._pool_sims:
+            self._engine.close()  # a longer search than the pools were sized for: new storage, the tree restarts
+            self._engine, self._root_key = None, None
         if self._engine is None:
             if neural and self._hipnet is None:
                 self._hipnet = self._nn.to_hip(max_batch=16)
@@ -136,7 +141,11 @@ class MCT:
                                           noise_mode=NOISE_PHILOX if noisy else NOISE_OFF,
                                           evaluator=EVAL_NET if neural else EVAL_ROLLOUT,
                                           seed=self._seed, sample_capacity=4 * H * W + 16, max_plies=4 * H * W + 16,
-                                          node_capacity=1 << 21)  # one slot: room for long compute_time searches
+                                          # one slot.  With a simulation count the pools hold the kept subtree plus one
+                                          # search (<= 65 new nodes per simulation, compacted at every move); searches
+                                          # bounded by wall time get 2 x 64 MiB
+                                          node_capacity=(1 << 21) if n_sim is None else max(1 << 14, min(1 << 21, 160 * n_sim)))
+            self._pool_sims = 0 if n_sim is None else max(n_sim, (1 << 14) // 160)
             self._plies = 0
         key = (board.grid.astype(np.int8).tobytes(), int(board.player))
         if key != self._root_key:  # tree restarted from an unexplored state (mcts.py:124-125, 231-233)

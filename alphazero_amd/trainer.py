@@ -68,6 +68,7 @@ class AlphaZeroTrainer:
         self.verbose = verbose
         self.engine_slots, self.seed = engine_slots, seed
         self._engine = self._hipnet = None
+        self.prev_nn = None
         self.device_samples = None  # the last self-play wave as CUDA tensors (state, pi, z, meta, visits)
         self.device_memory = None   # originals + symmetry twins as CUDA tensors: what optimize_network trains on
         # list[Sample] like the reference's trainer.memory; switch off for large runs (millions of Python objects)
@@ -205,8 +206,6 @@ class AlphaZeroTrainer:
             else:
                 self.nn_twin = self.nn.clone()
                 self.loss_values[iter_idx] = {}
-            if next(self.nn_twin.parameters()).device.type != "cuda" and torch.distributed.get_backend() == "nccl":
-                raise ValueError("distributed training over RCCL needs config.device = 'cuda'")
             broadcast_state_dict(self.nn_twin, src=0)
             return
         self._optimize_local(iter_idx)
@@ -287,6 +286,8 @@ class AlphaZeroTrainer:
         return pi_log.cpu().tolist(), v_log.cpu().tolist()
 
     def update_network(self, iter_idx):
+        if self.config.do_eval and self.config.eval_opponent == "previous":
+            self.prev_nn = self.nn  # the network this iteration's self-play used: the evaluation opponent
         self.nn = self.nn_twin.clone()
         self.nn_twin = None
         self.az_player.mct.nn = self.nn
@@ -296,6 +297,13 @@ class AlphaZeroTrainer:
         if not self.config.do_eval:
             return
         opp = self.config.eval_opponent
+        if opp == "previous":
+            # extension (BASELINE config 5, "arena eval vs prev net"): the freshly trained network against the one it
+            # replaces, all games at once on the GPU; "alphazero" keeps the reference's refusal (trainer.py:399-400)
+            if self.config.simulations is None:
+                raise ValueError("Evaluation against the previous network needs config.simulations.")
+            self.eval_results = {"eval_opponent": opp, "eval_episodes": self.config.eval_episodes, "results": {}}
+            return
         if opp not in PLAYERS_SET:
             raise ValueError(f"Opponent player '{opp}' not found in the players register.")
         if opp == "human":
@@ -305,27 +313,39 @@ class AlphaZeroTrainer:
         self.eval_results = {"eval_opponent": opp, "eval_episodes": self.config.eval_episodes, "results": {}}
 
     def evaluate(self, iter_idx):
-        if not self.config.do_eval or self._dist()[0] != 0:  # in a multi-GPU job rank 0 evaluates and writes the files
+        if not self.config.do_eval:
             return
-        eval_player = AlphaZeroPlayer(n_sim=self.config.simulations, compute_time=self.config.compute_time, nn=self.nn)
-        if self.config.eval_opponent in ("random", "greedy", "mcts") and self.config.simulations is not None:
-            # all evaluation games at once on the GPU (same stats dict as Arena.play_games)
+        c = self.config
+        rank, world = self._dist()
+        batched = c.eval_opponent in ("random", "greedy", "mcts", "previous") and c.simulations is not None
+        if not batched and rank != 0:  # host Arena: rank 0 plays; the batched arena below shards its rounds over all ranks
+            return
+        if batched:
+            # all evaluation games at once on the GPU(s) (same stats dict as Arena.play_games)
             from .arena import BatchedArena
-            c = self.config
-            opponent = PLAYERS_REGISTER[c.eval_opponent](**({"n_sim": c.simulations} if c.eval_opponent == "mcts" else {}))
-            arena = BatchedArena(self.game, self.nn, opponent=c.eval_opponent, n_sim=c.simulations, seed=self.seed + iter_idx,
+            if c.eval_opponent == "previous":
+                opp_arg, p2_name = self.prev_nn, "AlphaZeroPlayer(previous network)"
+            else:
+                opp_arg = c.eval_opponent
+                p2_name = f"{PLAYERS_REGISTER[c.eval_opponent](**({'n_sim': c.simulations} if c.eval_opponent == 'mcts' else {}))}"
+            arena = BatchedArena(self.game, self.nn, opponent=opp_arg, n_sim=c.simulations, seed=self.seed + iter_idx,
                                  board_size=getattr(c, "board_size", None), board_width=getattr(c, "board_width", 7),
                                  board_height=getattr(c, "board_height", 6))
             stats = arena.play_games(n_rounds=c.eval_episodes, return_stats=True)
+            p1_name = f"{type(self.az_player).__name__}"
         else:
-            kwargs = {"n_sim": self.config.simulations} if self.config.eval_opponent == "mcts" else {}
-            opponent = PLAYERS_REGISTER[self.config.eval_opponent](**kwargs)
-            arena = Arena(player1=eval_player, player2=opponent, board=BOARDS_REGISTER[self.game](config=self.config))
-            stats = arena.play_games(n_rounds=self.config.eval_episodes, return_stats=True)
+            eval_player = AlphaZeroPlayer(n_sim=c.simulations, compute_time=c.compute_time, nn=self.nn)
+            kwargs = {"n_sim": c.simulations} if c.eval_opponent == "mcts" else {}
+            opponent = PLAYERS_REGISTER[c.eval_opponent](**kwargs)
+            arena = Arena(player1=eval_player, player2=opponent, board=BOARDS_REGISTER[self.game](config=c))
+            stats = arena.play_games(n_rounds=c.eval_episodes, return_stats=True)
+            p1_name, p2_name = f"{eval_player}", f"{opponent}"
+        if rank != 0:
+            return
         for key in ("player1", "player2", "draw"):
             stats.pop(key, None)
         self.eval_results["results"][iter_idx] = {k: dict(v) for k, v in stats.items()}
-        self.eval_results["player1"], self.eval_results["player2"] = f"{eval_player}", f"{opponent}"
+        self.eval_results["player1"], self.eval_results["player2"] = p1_name, p2_name
 
     # ------------------------------------------------------------------ persistence (trainer.py:448-473)
     def _model_dir(self, model_name, path):
@@ -383,8 +403,13 @@ class AlphaZeroTrainer:
     def setup(self):
         """objects train() creates before the loop (trainer.py:500-518); needs self.game and self.config"""
         c = self.config
+        rank, world = self._dist()
+        if world > 1 and torch.distributed.get_backend() == "nccl" and torch.device(c.device).type != "cuda":
+            # fail before the first self-play wave, not after rank 0 has trained (the weight broadcast runs over RCCL)
+            raise ValueError("distributed training over RCCL needs config.device = 'cuda'")
         self.board = BOARDS_REGISTER[self.game](config=c)
         self.nn = NETWORKS_REGISTER[self.game](config=c)
+        self.prev_nn = None
         self.az_player = AlphaZeroPlayer(n_sim=c.simulations, compute_time=c.compute_time, nn=self.nn,
                                          dirichlet_alpha=c.dirichlet_alpha, dirichlet_epsilon=c.dirichlet_epsilon)
         self.temp_scheduler = TEMP_SCHEDULERS[c.temp_scheduler_type](temp_max_step=c.temp_max_step, temp_min_step=c.temp_min_step,

@@ -79,6 +79,12 @@ int az_net_set_tensor(az_net *net, const char *name, const float *h_data, int64_
 /* folds eval-mode BatchNorm into the preceding layer (float64), re-tiles the weights into MFMA
  * fragment order and uploads them.  Must be called after all tensors are set / updated. */
 int az_net_commit(az_net *net, void *stream);
+/* The same hand-off without a host round trip (update_network, trainer.py:383-387, when the trained module lives on the
+ * GPU): d_data is a DEVICE float32 tensor, copied on `stream`; az_net_commit_device folds BatchNorm and re-tiles with
+ * device kernels on `stream` (same float64 operation order as az_net_commit: identical bits).  A commit uses the
+ * tensors of ITS kind only: set every tensor through the same path. */
+int az_net_set_tensor_device(az_net *net, const char *name, const float *d_data, int64_t numel, void *stream);
+int az_net_commit_device(az_net *net, void *stream);
 /* d_input[B][H*W] float32 canonical boards (player*grid, base.py:363);
  * d_probs[B][A] = exp(log_softmax) policy, d_value[B] = tanh value. */
 int az_net_forward(az_net *net, const float *d_input, int B, float *d_probs, float *d_value, void *stream);
@@ -121,6 +127,9 @@ typedef struct {
     int64_t games_done, samples, net_evals, lockstep_iters, plies;
     int32_t max_nodes_used, error_flags;
     int64_t graph_replays;  /* searches issued as one HIP graph launch since the engine was created */
+    int32_t max_path_len;   /* longest root..leaf path (nodes) of a simulation since the last run/set_roots; only paths
+                               longer than 16 nodes are recorded (they take the parent-chasing back-propagation), else 0 */
+    int32_t reserved;
 } az_engine_stats;
 
 /* `stream` (hipStream_t, may be the default stream): the stream the caller's own work is queued on.  The engine runs on a
@@ -159,7 +168,8 @@ int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_actions, int3
  * then only touches slots where that colour is to move.  az_engine_best_moves = MCT.get_action_probs(temp = 0) for
  * those slots (-1 elsewhere); az_engine_baseline_moves = RandomPlayer (kind 0) / GreedyPlayer (kind 1)
  * (players.py:76-123) for the slots where the OTHER colour is to move; az_engine_play applies a move vector
- * (-1 = none) to the boards and trees; az_engine_root_status reads every slot's position back. */
+ * (-1 = none) to the boards and trees; az_engine_root_status reads every slot's position back (h_score = Board.get_score of
+ * the side to move: sum(player*grid) for Othello / Connect4; TicTacToe 32767 for the reference's +inf, tictactoe.py:119-126, else 0). */
 int az_engine_set_sides(az_engine *e, const int8_t *h_sides, int32_t n);
 int az_engine_best_moves(az_engine *e, int32_t *h_actions);
 int az_engine_baseline_moves(az_engine *e, int32_t kind, uint32_t seed, int32_t *h_actions);

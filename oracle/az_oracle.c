@@ -684,6 +684,8 @@ struct orc_mct {
     int ply, sim;
     int64_t n_evals;
     int n_rollouts;
+    int max_path; /* longest root..leaf path (nodes) any simulation walked: lets tests prove they reach deep paths */
+    int rng_exhausted; /* the Gamma rejection sampler gave up (never observed; reported, not hidden) */
 };
 
 static int new_node(orc_mct *t, int action, int parent, double P, int p_is_f32) {
@@ -717,12 +719,14 @@ void orc_mct_destroy(orc_mct *t) { if (t) { free(t->nodes); free(t->probs); free
 void orc_mct_reset(orc_mct *t, uint32_t game_id) { /* players.py:228-234 : fresh MCT, same nn */
     t->cfg.game_id = game_id;
     t->n_nodes = 0; t->n_probs = 0; t->ply = 0; t->sim = 0; t->n_evals = 0; t->n_rollouts = 0;
+    t->max_path = 0; t->rng_exhausted = 0;
     t->root = new_node(t, -1, -1, 0.0, 0);
 }
 void orc_mct_set_ply(orc_mct *t, int ply) { t->ply = ply; }
 int orc_mct_root_n(const orc_mct *t) { return t->nodes[t->root].N; }
 int orc_mct_n_nodes(const orc_mct *t) { return t->n_nodes; }
 int64_t orc_mct_n_evals(const orc_mct *t) { return t->n_evals; }
+int orc_mct_max_path_len(const orc_mct *t) { return t->max_path; }
 
 static uint32_t rng_below(const orc_mct *t, int purpose, uint32_t idx, uint32_t n) {
     uint32_t r[4];
@@ -779,12 +783,14 @@ static void expand_neural(orc_mct *t, int node, const orc_board *b) {
 static int select_node(orc_mct *t, orc_board *b) { /* mcts.py:127-171 */
     int node = t->root;
     uint32_t depth = 0;
+#define PATH_SEEN(nodes_on_path) do { if ((int)(nodes_on_path) > t->max_path) t->max_path = (int)(nodes_on_path); } while (0)
     while (t->nodes[node].n_children != 0) {
         int c = pick_child(t, node, depth++);
         if (orc_play(b, t->nodes[c].action) != 0) return -1;
         node = c;
-        if (t->nodes[node].N == 0) return node;
+        if (t->nodes[node].N == 0) { PATH_SEEN(depth + 1); return node; }
     }
+    PATH_SEEN(depth + 1);
     if (orc_is_over(b)) return node;
     if (t->cfg.eval_method == ORC_EVAL_ROLLOUT) {
         int legal[ORC_MAX_ACTIONS];
@@ -794,13 +800,16 @@ static int select_node(orc_mct *t, orc_board *b) { /* mcts.py:127-171 */
         t->nodes[node].first_child = first; t->nodes[node].n_children = k;
         int c = first + (int)rng_below(t, P_ROLLOUT_EXPAND, depth, (uint32_t)k); /* mcts.py:163-165 */
         if (orc_play(b, t->nodes[c].action) != 0) return -1;
+        PATH_SEEN(depth + 2);
         return c;
     }
     if (t->nodes[node].probs_off < 0) return -1; /* "should not happen", mcts.py:157 */
     expand_neural(t, node, b);
     int c = pick_child(t, node, depth);
     if (orc_play(b, t->nodes[c].action) != 0) return -1;
+    PATH_SEEN(depth + 2);
     return c;
+#undef PATH_SEEN
 }
 
 static void back_propagate(orc_mct *t, int node, int player_id, double outcome) { /* mcts.py:197-223 */
@@ -819,8 +828,9 @@ static void back_propagate(orc_mct *t, int node, int player_id, double outcome) 
 /* Gamma(alpha) for the Dirichlet draw, in log space: Marsaglia-Tsang on alpha+1 with the
  * U^(1/alpha) boost; normals by the polar method.  Statistically equal to np.random.dirichlet
  * (mcts.py:238); bit-equal to the HIP engine. */
-static double log_gamma_draw(const orc_mct *t, double alpha, uint32_t j) {
+static double log_gamma_draw(orc_mct *t, double alpha, uint32_t j) {
     double d = (alpha + 1.0) - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d), g = d;
+    int accepted = 0;
     for (uint32_t att = 0; att < 64; ++att) {
         uint32_t r[4], q[4];
         orc_philox4x32(t->cfg.seed, t->cfg.game_id, (uint32_t)t->ply, (uint32_t)t->sim, P_NOISE_NORMAL, j | (att << 8), r);
@@ -833,8 +843,9 @@ static double log_gamma_draw(const orc_mct *t, double alpha, uint32_t j) {
         if (!(v > 0.0)) continue;
         v = v * v * v;
         double u = 1.0 - u53(q[0], q[1]);
-        if (orc_det_log(u) < 0.5 * x * x + d - d * v + d * orc_det_log(v)) { g = d * v; break; }
+        if (orc_det_log(u) < 0.5 * x * x + d - d * v + d * orc_det_log(v)) { g = d * v; accepted = 1; break; }
     }
+    if (!accepted) t->rng_exhausted = 1; /* p < 1e-38 per draw; the search then fails instead of using g = d */
     uint32_t r[4];
     orc_philox4x32(t->cfg.seed, t->cfg.game_id, (uint32_t)t->ply, (uint32_t)t->sim, P_NOISE_BOOST, j, r);
     double ub = 1.0 - u53(r[0], r[1]);
@@ -920,6 +931,7 @@ int orc_mct_search(orc_mct *t, const orc_board *root, int n_sim) { /* mcts.py:25
     for (int i = 0; i < n_sim; ++i) {
         t->sim = i;
         if (search_iter(t, root) != 0) return -1;
+        if (t->rng_exhausted) return -1;
     }
     return 0;
 }
@@ -980,6 +992,31 @@ int orc_mct_choose(orc_mct *t, const orc_board *rootb, double temp, double *pi, 
         if (u < cum) return t->nodes[r->first_child + i].action;
     }
     return t->nodes[r->first_child + last].action;
+}
+
+/* RandomPlayer (kind 0, players.py:76-94: board.get_random_move) / GreedyPlayer (kind 1, players.py:97-123: best
+ * -get_score() of the position after the move, fair_max among equals) for the side to move.  The uniform draw among the
+ * candidates (ascending action order) is keyed like the HIP engine's k_baseline_moves. */
+int orc_baseline_move(const orc_board *b, int kind, uint32_t seed, uint32_t game_id, int ply) {
+    int legal[ORC_MAX_ACTIONS], cand[ORC_MAX_ACTIONS], nc = 0;
+    int k = orc_legal_moves(b, 0, legal);
+    if (k <= 0) return -1;
+    if (b->game == ORC_OTHELLO && legal[0] == orc_pass_action(b)) return legal[0]; /* forced pass: no draw */
+    if (kind == 0) { for (int i = 0; i < k; ++i) cand[nc++] = legal[i]; }
+    else {
+        int best = -1000000;
+        for (int i = 0; i < k; ++i) {
+            orc_board c = *b;
+            orc_play(&c, legal[i]);
+            int sc = orc_score(&c);
+            sc = (b->game == ORC_TICTACTOE) ? (sc != 0 ? -1 : 0) : -sc; /* -inf compares below 0 */
+            if (sc > best) { best = sc; nc = 0; }
+            if (sc == best) cand[nc++] = legal[i];
+        }
+    }
+    uint32_t r[4];
+    orc_philox4x32(seed, game_id, (uint32_t)ply, 0xFFFEu, P_TIE_MOVE, (uint32_t)kind, r);
+    return cand[(uint32_t)(((uint64_t)r[0] * (uint32_t)nc) >> 32)];
 }
 
 /* ======================================================================== */

@@ -122,6 +122,9 @@ int orc_mct_root_children(const orc_mct *t, int *actions, int *N, double *Q, dou
 int orc_mct_choose(orc_mct *t, const orc_board *root, double temp, double *pi, int *visits);
 int orc_mct_n_nodes(const orc_mct *t);
 int64_t orc_mct_n_evals(const orc_mct *t);
+int orc_mct_max_path_len(const orc_mct *t); /* longest root..leaf path (in nodes) of any simulation since the last reset */
+/* RandomPlayer (kind 0) / GreedyPlayer (kind 1) move for the side to move (players.py:76-123); -1 if no move */
+int orc_baseline_move(const orc_board *b, int kind, uint32_t seed, uint32_t game_id, int ply);
 
 /* ---- self-play (trainer.py:215-273) -------------------------------------- */
 typedef struct {

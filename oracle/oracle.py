@@ -115,6 +115,8 @@ def lib():
     L.orc_mct_n_nodes.argtypes = [C.c_void_p]
     L.orc_mct_n_evals.argtypes = [C.c_void_p]
     L.orc_mct_n_evals.restype = C.c_int64
+    L.orc_mct_max_path_len.argtypes = [C.c_void_p]
+    L.orc_baseline_move.argtypes = [bp, C.c_int, C.c_uint32, C.c_uint32, C.c_int]
     L.orc_selfplay.argtypes = [C.POINTER(SelfplayCfg), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     L.orc_selfplay.restype = C.c_int64
@@ -147,6 +149,11 @@ def legal_moves(b, player=0):
     out = (C.c_int * 65)()
     k = lib().orc_legal_moves(C.byref(b), player, out)
     return list(out[:k])
+
+
+def baseline_move(b, kind, seed, game_id, ply):
+    """RandomPlayer ('random') / GreedyPlayer ('greedy') move for the side to move (players.py:76-123)"""
+    return lib().orc_baseline_move(C.byref(b), {"random": 0, "greedy": 1}[kind], seed, game_id, ply)
 
 
 def fakenet(b):
@@ -221,9 +228,12 @@ class MlpNet:
         return probs, v
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_mlpnet_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().orc_mlpnet_destroy(self.h)
+                self.h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class MCT:
@@ -261,6 +271,13 @@ class MCT:
     def root_n(self):
         return lib().orc_mct_root_n(self.h)
 
+    def max_path_len(self):
+        """longest root..leaf path (in nodes) any simulation of this tree has walked"""
+        return lib().orc_mct_max_path_len(self.h)
+
+    def reset(self, game_id):
+        lib().orc_mct_reset(self.h, game_id)
+
     def choose(self, board, temp):
         A = lib().orc_action_size(C.byref(board))
         pi = np.zeros(65, np.float64); vis = np.zeros(65, np.int32)
@@ -268,9 +285,12 @@ class MCT:
         return act, pi[:A].copy(), vis[:A].copy()
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_mct_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().orc_mct_destroy(self.h)
+                self.h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 def selfplay(game_id, H, W, n_games, n_sim, evaluator=("fake", None), alpha=0.03, eps=0.25,

@@ -28,6 +28,21 @@ def _worker(rank, world, port, ret):
         ok &= bool((out["z"][off:off + s] == r).all()) and bool((out["state"][off:off + s] == r).all())
         ok &= int(out["meta"][off, 0]) == (3 * world + r) * 5
         off += s
+    # a rank without samples (fewer episodes than ranks) and the flat weight broadcast
+    S2 = 0 if rank == 1 else 4
+    out2 = all_gather_samples({"z": torch.full((S2,), rank, dtype=torch.int8), "pi": torch.full((S2, 9), float(rank))})
+    ok &= out2["z"].shape[0] == 4 and out2["pi"].shape == (4, 9) and bool((out2["z"] == 0).all())
+    from alphazero_amd.dist import all_gather_rows, broadcast_state_dict
+    torch.manual_seed(rank)
+    bn = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3))
+    bn[1].num_batches_tracked += 7 * (rank + 1)
+    broadcast_state_dict(bn, src=0)
+    torch.manual_seed(0)
+    want = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3))
+    ok &= all(torch.equal(a, b) for a, b in zip(bn.state_dict().values(), want.state_dict().values()) if a.dtype == torch.float32)
+    ok &= int(bn[1].num_batches_tracked) == 7
+    rows = all_gather_rows(torch.full((3, 2), rank, dtype=torch.int32))
+    ok &= rows.shape == (3 * world, 2) and bool((rows[3:] == 1).all()) and bool((rows[:3] == 0).all())
     ret[rank] = (ok, first, cnt)
     dist.destroy_process_group()
 
@@ -47,3 +62,24 @@ def test_single_process_passthrough():
     from alphazero_amd.dist import all_gather_samples
     d = {"z": torch.zeros(3)}
     assert all_gather_samples(d) is d
+
+
+def _worker_one(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    sys.path.insert(0, ROOT)
+    from alphazero_amd.dist import all_gather_rows, all_gather_samples
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    smp = {"state": torch.arange(5 * 9, dtype=torch.int8).view(5, 3, 3), "pi": torch.rand(5, 9), "z": torch.ones(5, dtype=torch.int8),
+           "meta": torch.arange(20, dtype=torch.int32).view(5, 4)}
+    same = all_gather_samples(smp)
+    forced = all_gather_samples(smp, force=True)  # the collective path with one rank: what a 1-GPU box can rehearse
+    ret[0] = (same is smp) and forced is not smp and all(torch.equal(forced[k], smp[k]) and forced[k].dtype == smp[k].dtype for k in smp) \
+        and torch.equal(all_gather_rows(smp["meta"], force=True), smp["meta"])
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_world1_gloo():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_one, args=(1, 29534, ret), nprocs=1, join=True)
+    assert ret[0]

@@ -1,0 +1,148 @@
+"""GPU parity of the batched arena (arena.py:36-185, trainer.py:408-446): every game BatchedArena plays
+is replayed by the CPU oracle driven exactly as Arena.play_game drives its players -- each side owns a tree, BOTH trees
+receive every move (arena.py:98-99), the AlphaZero side searches without noise at temperature 0 (trainer.py:421-425),
+the opponent is RandomPlayer / GreedyPlayer (players.py:76-123), rollout MCTSPlayer, or another network -- and must
+produce the same move at every ply, the same winners and the same stats dict."""
+import ctypes as C
+from collections import defaultdict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from alphazero_amd.arena import BatchedArena
+
+pytestmark = pytest.mark.gpu
+
+
+def _np_sd(module):
+    return {k: v.detach().cpu().numpy() for k, v in module.state_dict().items() if not k.endswith("num_batches_tracked")}
+
+
+def _nets(game, seed):
+    from alphazero_amd.games.connect4 import Connect4Net
+    from alphazero_amd.games.othello import OthelloNet
+    from alphazero_amd.games.tictactoe import TicTacToeNet
+    torch.manual_seed(seed)
+    if game == "othello":
+        net = OthelloNet(n=6).eval()
+        return net, ("conv", O.ConvNet(O.OTHELLO, 6, 6, _np_sd(net))), (O.OTHELLO, 6, 6)
+    if game == "connect4":
+        net = Connect4Net(7, 6).eval()
+        return net, ("conv", O.ConvNet(O.CONNECT4, 6, 7, _np_sd(net))), (O.CONNECT4, 6, 7)
+    net = TicTacToeNet().eval()
+    return net, ("mlp", O.MlpNet(_np_sd(net))), (O.TICTACTOE, 3, 3)
+
+
+def oracle_arena(dims, ev1, n_sim, opponent, opp_sim, seed, n_rounds, start_player=None):
+    """Arena.play_games restated on the oracle; returns (moves per game, winners, scores, stats dict)"""
+    gid, H, W = dims
+    p2_starts = [{1: False, 2: True}.get(start_player, bool(r % 2)) for r in range(n_rounds)]
+    all_moves, winners, scores = [], [], []
+    for r in range(n_rounds):
+        side1 = -1 if p2_starts[r] else 1
+        game_id = (r + seed * 100003) & 0xFFFFFFFF
+        t1 = O.MCT(ev1, eval_method=O.EVAL_NEURAL, tie_mode=O.TIE_RANDOM, noise_mode=O.NOISE_OFF, seed=seed, game_id=game_id)
+        t2 = None
+        if opponent == "mcts":
+            t2 = O.MCT(("fake", None), eval_method=O.EVAL_ROLLOUT, tie_mode=O.TIE_RANDOM, noise_mode=O.NOISE_OFF, seed=seed + 1, game_id=game_id)
+        elif not isinstance(opponent, str):
+            t2 = O.MCT(opponent, eval_method=O.EVAL_NEURAL, tie_mode=O.TIE_RANDOM, noise_mode=O.NOISE_OFF, seed=seed + 1, game_id=game_id)
+        b = O.new_board(gid, H, W)
+        ply, moves = 0, []
+        while not O.lib().orc_is_over(C.byref(b)):
+            mine = b.player == side1
+            if mine or t2 is not None:
+                t, ns = (t1, n_sim) if mine else (t2, opp_sim)
+                t.set_ply(ply)
+                t.search(b, ns)
+                a = t.choose(b, 0.0)[0]
+            else:
+                a = O.baseline_move(b, opponent, seed + 7, game_id, ply)
+            assert O.lib().orc_play(C.byref(b), a) == 0
+            t1.change_root(a)           # arena.py:98-99: both players are told every move
+            if t2 is not None:
+                t2.change_root(a)
+            moves.append(a)
+            ply += 1
+        w = C.c_int()
+        O.lib().orc_winner(C.byref(b), C.byref(w))
+        all_moves.append(moves); winners.append(w.value)
+        sc = abs(O.lib().orc_score(C.byref(b)))
+        scores.append(float("inf") if gid == O.TICTACTOE and sc == 32767 else sc)
+    stats = {"player1": [], "player2": [], "draw": 0, "player1_starts": defaultdict(int), "player2_starts": defaultdict(int)}
+    for r in range(n_rounds):
+        starter = f"player{2 if p2_starts[r] else 1}_starts"
+        if winners[r] == 0:
+            stats["draw"] += 1
+            stats[starter]["draw"] += 1
+        else:
+            who = 1 if winners[r] == (-1 if p2_starts[r] else 1) else 2
+            stats[f"player{who}"].append(scores[r])
+            stats[starter]["win" if who == (2 if p2_starts[r] else 1) else "loss"] += 1
+    return all_moves, winners, scores, stats
+
+
+def _check(game, opponent_kind, n_rounds, n_sim, opp_sim, seed):
+    net, ev1, dims = _nets(game, 20 + seed)
+    if opponent_kind == "network":
+        net2, ev2, _ = _nets(game, 40 + seed)
+        opp_engine, opp_oracle = net2, ev2
+    else:
+        opp_engine = opp_oracle = opponent_kind
+    arena = BatchedArena(game, net, opponent=opp_engine, n_sim=n_sim, opponent_n_sim=opp_sim, seed=seed, board_size=6)
+    stats = arena.play_games(n_rounds, return_stats=True, record_moves=True)
+    got = [[int(m[g]) for m in arena.moves if m[g] >= 0] for g in range(n_rounds)]
+    moves, winners, scores, ostats = oracle_arena(dims, ev1, n_sim, opp_oracle, opp_sim, seed, n_rounds)
+    for g in range(n_rounds):
+        assert got[g] == moves[g], (game, opponent_kind, g, got[g], moves[g])
+    assert stats["draw"] == ostats["draw"] and sorted(stats["player1"]) == sorted(ostats["player1"])
+    assert sorted(stats["player2"]) == sorted(ostats["player2"])
+    assert dict(stats["player1_starts"]) == dict(ostats["player1_starts"]) and dict(stats["player2_starts"]) == dict(ostats["player2_starts"])
+    return stats
+
+
+@pytest.mark.parametrize("game", ["othello", "connect4", "tictactoe"])
+@pytest.mark.parametrize("opponent", ["random", "greedy", "mcts"])
+def test_batched_arena_equals_oracle_arena(game, opponent):
+    stats = _check(game, opponent, n_rounds=32, n_sim=16, opp_sim=24, seed=3)
+    assert len(stats["player1"]) + len(stats["player2"]) + stats["draw"] == 32
+
+
+@pytest.mark.parametrize("game", ["othello", "connect4"])
+def test_batched_arena_network_vs_network_equals_oracle(game):
+    """evaluation against another network (eval_opponent = "previous"): two device trees per game, both re-rooted at every move"""
+    _check(game, "network", n_rounds=16, n_sim=20, opp_sim=12, seed=5)
+
+
+def test_trainer_evaluates_against_the_previous_network(tmp_path):
+    """BASELINE config 5 "arena eval vs prev net": eval_opponent = "previous" plays the trained network against the one it
+    replaces; "alphazero" keeps the reference's refusal (trainer.py:399-400)"""
+    import json
+    import os
+    from alphazero_amd import base
+    from alphazero_amd.games.othello import OthelloConfig
+    from alphazero_amd.trainer import AlphaZeroTrainer
+    base.DEFAULT_MODELS_PATH = str(tmp_path) + "/"
+    tr = AlphaZeroTrainer(verbose=False, engine_slots=16, seed=1, materialize_memory=False)
+    tr.game = "othello"
+    tr.config = OthelloConfig(board_size=6, simulations=8, episodes=16, epochs=1, batch_size=32, iterations=1, do_eval=True,
+                              eval_opponent="alphazero", eval_episodes=8)
+    with pytest.raises(ValueError, match="not yet implemented"):
+        tr.setup()
+    tr.config.eval_opponent = "previous"
+    tr.setup()
+    first = tr.nn
+    tr.self_play(0); tr.optimize_network(0); tr.update_network(0)
+    assert tr.prev_nn is first and tr.nn is not first
+    tr.evaluate(0)
+    res = tr.eval_results["results"][0]
+    assert sum(sum(v.values()) for v in res.values()) == 8 and tr.eval_results["eval_opponent"] == "previous"
+    # the same games, replayed by the oracle with the two weight sets
+    ev_new = ("conv", O.ConvNet(O.OTHELLO, 6, 6, _np_sd(tr.nn)))
+    ev_old = ("conv", O.ConvNet(O.OTHELLO, 6, 6, _np_sd(first)))
+    _, _, _, ostats = oracle_arena((O.OTHELLO, 6, 6), ev_new, 8, ev_old, 8, tr.seed + 0, 8)
+    assert res == {k: dict(v) for k, v in ostats.items() if k.endswith("_starts")}
+    tr.save_training_stats("prev-test")
+    assert json.load(open(os.path.join(tmp_path, "prev-test", "eval.json")))["eval_opponent"] == "previous"
