@@ -446,26 +446,28 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     PSTAMP(0)
-    if (g >= g1) {  // out-of-range group: nothing to do, but it must still meet the block's barriers below
-        if (SELECT) { __shared__ int dummy; (void)dummy; __syncthreads(); __syncthreads(); __syncthreads(); }
-        return;
-    }
+    // Groups beyond the last slot (the slot count need not fill the last wavefront / block) stay in the kernel as
+    // inert groups: every __syncthreads() below must be reached by all waves of the block the same number of times, and
+    // an early return -- or barriers in a divergent branch -- of SOME lanes of a wavefront breaks exactly that (the
+    // wave would arrive twice per barrier: leaf rows were then handed out before all groups had asked for one).
+    const bool in_range = g < g1;
+    const int gs = in_range ? g : g1 - 1;  // a valid index for the (unused) loads of an inert group
     // ---- every per-slot word is fetched here, in one batch of independent loads: the kernel is bound by
     // ---- the number of DEPENDENT memory round trips (~1 us each), not by bytes
-    Node *pool = pool_of(E, g);
-    const int st = BACKUP ? E.leaf_status[g] : LS_NONE;
-    const int leaf = BACKUP ? E.leaf[g] : 0;
-    const BB lb = {BACKUP ? E.leaf_p1[g] : 0, BACKUP ? E.leaf_m1[g] : 0, BACKUP ? E.leaf_player[g] : 1};
-    const int row_prev = BACKUP ? E.row_of_slot[g] : 0;
-    const int plen_prev = BACKUP ? E.path_len[g] : 0;
-    const int path_prev = BACKUP ? E.path[(size_t)g * LPG + sub] : 0;
-    const int lwin = BACKUP ? E.leaf_winner[g] : 0;
-    int n_nodes = E.n_nodes[g];
-    int evals = E.evals[g];
-    bool active = searches(E, g);
-    const int ply = E.ply[g];
-    BB b = {E.root_p1[g], E.root_m1[g], E.root_player[g]};
-    int node = E.root[g];
+    Node *pool = pool_of(E, gs);
+    const int st = (BACKUP && in_range) ? E.leaf_status[gs] : LS_NONE;
+    const int leaf = BACKUP ? E.leaf[gs] : 0;
+    const BB lb = {BACKUP ? E.leaf_p1[gs] : 0, BACKUP ? E.leaf_m1[gs] : 0, BACKUP ? E.leaf_player[gs] : 1};
+    const int row_prev = BACKUP ? E.row_of_slot[gs] : 0;
+    const int plen_prev = BACKUP ? E.path_len[gs] : 0;
+    const int path_prev = BACKUP ? E.path[(size_t)gs * LPG + sub] : 0;
+    const int lwin = BACKUP ? E.leaf_winner[gs] : 0;
+    int n_nodes = E.n_nodes[gs];
+    int evals = E.evals[gs];
+    bool active = in_range && searches(E, gs);
+    const int ply = E.ply[gs];
+    BB b = {E.root_p1[gs], E.root_m1[gs], E.root_player[gs]};
+    int node = E.root[gs];
     Node fwd;
     bool have_root = false;
     PSTAMP(1)
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
     PSTAMP(3)
-    if (BACKUP && sub == 0) E.evals[g] = evals;
+    if (BACKUP && sub == 0 && in_range) E.evals[g] = evals;
     if (!SELECT) return;
     // From here on no group may leave early: the leaf rows are handed out per BLOCK (one global atomic per
     // 16 games instead of one per game on a single hot address) behind two workgroup barriers.
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(256) void k_step(EngDev E, int sim, int g0, int g1)
         write_nn_input_grp(E, row, b, sub);
         if (sub == 0) E.row_of_slot[g] = row;
     }
-    if (sub == 0) {
+    if (sub == 0 && in_range) {
         if (active) { E.leaf[g] = node; E.leaf_p1[g] = b.p1; E.leaf_m1[g] = b.m1; E.leaf_player[g] = (int8_t)b.player; E.leaf_winner[g] = (int8_t)w; }
         E.leaf_status[g] = (int8_t)status;
     }

@@ -45,6 +45,23 @@ def test_selfplay_at_baseline_simulation_counts_equals_oracle(name, gid, H, W, g
         assert np.array_equal(got[k], ref[k]), k
 
 
+# ------------------------------------------------------------------------------------------------ ragged slot counts
+@pytest.mark.parametrize("slots", [1, 2, 3, 5, 6, 7, 13, 21, 30])
+def test_slot_counts_that_do_not_fill_a_wavefront(slots):
+    """16 lanes per game, 4 games per wavefront, 16 per workgroup: a slot count that leaves the last wavefront partly
+    empty once handed the leaf rows out before every game had asked for one (barriers in a divergent branch; found by
+    the uniform-prior test below running 6 slots).  Real network: the values of the affected slots went stale."""
+    from test_gpu_net import nets
+    fx, sd, onet, hnet = nets("othello6")
+    games = slots + 3
+    eng = E.SelfPlayEngine(0, 6, 6, n_slots=slots, n_sim=20, net=hnet, seed=31, sample_capacity=games * 72)
+    got = sort_samples(eng.run(games, first_game_id=7))
+    ref = O.selfplay(O.OTHELLO, 6, 6, games, 20, ("conv", onet), seed=31, first_game_id=7)
+    assert eng.stats()["net_evals"] == ref["n_evals"]
+    for k in ("state", "z", "meta", "visits", "pi"):
+        assert np.array_equal(got[k], ref[k]), k
+
+
 # ------------------------------------------------------------------------------------------------ deep paths
 def _late_positions(gid, H, W, seed, plies_lo, plies_hi, want, n_sim, tie, noise, alpha, eps):
     """random late positions whose oracle search walks paths of more than 16 nodes"""
@@ -230,9 +247,9 @@ def test_device_fold_equals_host_fold(tag):
 
 def test_plane_shapes_without_a_trunk_kernel_are_refused():
     """the reference builds OthelloNet for any even n and Connect4Net for any width x height >= 4x4 (othello.py:316-339,
-    connect4.py:343-368); the HIP trunk is instantiated for 8x8, 6x6 and 7x6 planes: everything else is AZ_EINVAL at
+    connect4.py:343-368); the HIP trunk is instantiated for 8x8, 6x6 and 7x6 planes (Othello 8 / 6, Connect4 6x7 and 8x8): everything else is AZ_EINVAL at
     az_net_create, never a silent mis-tiled launch"""
-    for gid, H, W in ((1, 5, 6), (1, 6, 8), (1, 8, 8), (0, 4, 4)):
+    for gid, H, W in ((1, 5, 6), (1, 6, 8), (1, 8, 7), (0, 4, 4)):
         h = C.c_void_p()
         rc = E.lib().az_net_create(gid, H, W, 64, C.byref(h))
         assert rc == E._lib.AZ_EINVAL and b"no conv-trunk kernel" in E.lib().az_last_error()
