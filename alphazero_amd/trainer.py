@@ -176,12 +176,17 @@ class AlphaZeroTrainer:
     def _n_samples(self):
         return self.device_memory["z"].shape[0] if self.device_memory is not None else len(self.memory)
 
+    def _permutation(self, n, device):
+        """the epoch's sample order (trainer.py:292-294 shuffles indexes with np.random); drawn on the device when the
+        memory lives there.  One place, so tests can pin the order to the reference's."""
+        return torch.randperm(n, device=device)
+
     def _batch_generator(self, n_batches):
         """random batches without replacement (trainer.py:288-318); device-resident when self_play ran on the engine"""
         bs, dev = self.config.batch_size, self.config.device
         if self.device_memory is not None:
             m = self.device_memory
-            idx = torch.randperm(m["z"].shape[0], device=m["z"].device)[: n_batches * bs].view(n_batches, bs)
+            idx = self._permutation(m["z"].shape[0], m["z"].device)[: n_batches * bs].view(n_batches, bs)
             for rows in idx:
                 yield (m["state"][rows].to(dev, torch.float32), m["pi"][rows].to(dev, torch.float32),
                        m["z"][rows].to(dev, torch.float32).unsqueeze(1))
@@ -251,7 +256,7 @@ class AlphaZeroTrainer:
         The learning rate is a host scalar inside the captured optimizer kernels, so the graph is re-captured every
         epoch (ExponentialLR, trainer.py:334).  Same arithmetic as _sgd_step; losses are read back once per epoch."""
         m, bs, dev = self.device_memory, self.config.batch_size, torch.device(self.config.device)
-        perm = torch.randperm(m["z"].shape[0], device=m["z"].device)[: n_batches * bs].view(n_batches, bs)
+        perm = self._permutation(m["z"].shape[0], m["z"].device)[: n_batches * bs].view(n_batches, bs)
         step_t = torch.zeros(1, dtype=torch.long, device=dev)
         pi_log = torch.zeros(n_batches, device=dev)
         v_log = torch.zeros(n_batches, device=dev)

@@ -47,3 +47,47 @@ def test_baseline_players_and_argument_errors():
     stats = Arena(GreedyPlayer(), RandomPlayer(), BOARDS_REGISTER["othello"](n=6)).play_games(40, return_stats=True)
     assert len(stats["player1"]) > len(stats["player2"])  # report Table 3: greedy beats random
     assert sum(stats["player1_starts"].values()) == 20 and sum(stats["player2_starts"].values()) == 20
+
+
+@pytest.mark.parametrize("tag", ["tictactoe", "connect4", "othello6"])
+def test_optimize_network_matches_reference_losses(tag):
+    """SURVEY 8f rank 3 / golden G6: AlphaZeroTrainer.optimize_network of the reference (trainer.py:320-381: loss
+    -sum(pi log p)/B + sum((v - z)^2)/B, SGD momentum 0.9, weight decay 1e-4, ExponentialLR 0.9, train-mode BatchNorm) run by
+    tools/gen_golden.py on the G4 memory with closed-form initial weights, dropout 0 and a pinned batch shuffle -> the
+    mirror's loop must log the same per-batch losses over two epochs and end with the same weights (1e-5)."""
+    import ast
+    import torch
+    from tools import closed_form as cf
+    from alphazero_amd.games.registers import CONFIGS_REGISTER
+    from alphazero_amd.trainer import AlphaZeroTrainer
+    torch.set_num_threads(1)
+    game, gid, H, W, A, n = TAGS[tag]
+    fx, mem_fx, net_fx = golden(f"sgd_{tag}.npz"), golden(f"selfplay_{tag}.npz"), golden(f"net_{tag}.npz")
+    extra = {"board_size": n} if game == "othello" else {}
+    cfg = CONFIGS_REGISTER[game](epochs=int(fx["epochs"]), batch_size=int(fx["batch_size"]), **extra)
+    assert cfg.learning_rate == float(fx["lr"])
+    tr = AlphaZeroTrainer(verbose=False)
+    tr.config, tr.game = cfg, game
+    net = NETWORKS_REGISTER[game](config=cfg)
+    shapes = {str(k): ast.literal_eval(str(v)) for k, v in zip(net_fx["shape_keys"], net_fx["shape_vals"])}
+    net.load_state_dict({k: torch.tensor(v) for k, v in cf.closed_form_state_dict(shapes).items()})
+    if hasattr(net, "dropout"):
+        net.dropout = 0.0
+    tr.nn = net
+    tr.memory = [Sample(state=mem_fx["state"][i].astype(np.float64), pi=mem_fx["pi"][i].copy(), player=1, outcome=int(mem_fx["outcome"][i]),
+                        episode_idx=int(mem_fx["episode_idx"][i]), move_idx=int(mem_fx["move_idx"][i])) for i in range(len(mem_fx["outcome"]))]
+    assert len(tr.memory) == int(fx["n_samples"])
+    tr.loss_values = {}
+    np.random.seed(int(fx["shuffle_seed"]))
+    tr.optimize_network(0)
+    for e in range(int(fx["epochs"])):
+        got_pi, got_v = np.array(tr.loss_values[0][e]["pi"]), np.array(tr.loss_values[0][e]["v"])
+        assert got_pi.shape == fx[f"pi_loss_{e}"].shape
+        assert np.abs(got_pi - fx[f"pi_loss_{e}"]).max() < 1e-5 and np.abs(got_v - fx[f"v_loss_{e}"]).max() < 1e-5
+    sd = tr.nn_twin.state_dict()
+    assert np.abs(sd["fc1.weight"].numpy()[:64] - fx["fc1_weight"]).max() < 1e-5
+    assert np.abs(sd["fc_value.weight"].numpy() - fx["fc_value_weight"]).max() < 1e-5
+    bn = ("fc_bn1" if game != "tictactoe" else "bn1") + ".running_mean"
+    assert np.abs(sd[bn].numpy() - fx["bn_running_mean"]).max() < 1e-5
+    # a wrong momentum / weight-decay constant must not pass: the fixture separates them
+    assert np.abs(fx["pi_loss_0"] - fx["pi_loss_1"][: len(fx["pi_loss_0"])]).max() > 1e-3

@@ -271,6 +271,51 @@ def test_graphed_sgd_equals_eager_sgd(tmp_path, monkeypatch):
     assert not torch.equal(out[True][0]["fc1.weight"], tr.nn.state_dict()["fc1.weight"].to("cuda"))
 
 
+@pytest.mark.parametrize("tag", ["tictactoe", "connect4", "othello6"])
+@pytest.mark.parametrize("graphed", [False, True])
+def test_device_sgd_matches_reference_fixture(tag, graphed):
+    """golden G6 on the GPU: optimize_network on DEVICE-resident samples (eager and as a replayed HIP graph) logs the
+    per-batch losses the reference's CPU loop logged (same initial weights, same batches in the same order, dropout 0)
+    over two epochs, and ends with the same weights.  float32 on two devices: 2e-4 on the losses (they are O(1)),
+    1e-4 on the weights."""
+    import ast
+    from conftest import TAGS, golden
+    from tools import closed_form as cf
+    from alphazero_amd.games.registers import CONFIGS_REGISTER, NETWORKS_REGISTER
+    game, gid, H, W, A, n = TAGS[tag]
+    fx, mem, net_fx = golden(f"sgd_{tag}.npz"), golden(f"selfplay_{tag}.npz"), golden(f"net_{tag}.npz")
+    extra = {"board_size": n} if game == "othello" else {}
+    cfg = CONFIGS_REGISTER[game](epochs=int(fx["epochs"]), batch_size=int(fx["batch_size"]), device="cuda", **extra)
+    tr = AlphaZeroTrainer(verbose=False)
+    tr.config, tr.game, tr.graph_sgd = cfg, game, graphed
+    net = NETWORKS_REGISTER[game](config=cfg)
+    shapes = {str(k): ast.literal_eval(str(v)) for k, v in zip(net_fx["shape_keys"], net_fx["shape_vals"])}
+    net.load_state_dict({k: torch.tensor(v) for k, v in cf.closed_form_state_dict(shapes).items()})
+    if hasattr(net, "dropout"):
+        net.dropout = 0.0
+    tr.nn = net.to("cuda")
+    dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+    tr.device_memory = {"state": dev(mem["state"], torch.int8), "pi": dev(mem["pi"].astype(np.float32), torch.float32),
+                        "z": dev(mem["outcome"], torch.int8), "meta": torch.zeros((len(mem["outcome"]), 4), dtype=torch.int32, device="cuda")}
+    rs = np.random.RandomState(int(fx["shuffle_seed"]))  # np.random.seed + np.random.shuffle of the reference's generator
+
+    def reference_order(n_samples, device):
+        idx = np.arange(n_samples)
+        rs.shuffle(idx)
+        return torch.as_tensor(idx, device=device)
+    tr._permutation = reference_order
+    tr.loss_values = {}
+    tr.optimize_network(0)
+    for e in range(int(fx["epochs"])):
+        for k in ("pi", "v"):
+            got = np.array(tr.loss_values[0][e][k])
+            assert got.shape == fx[f"{k}_loss_{e}"].shape
+            assert np.abs(got - fx[f"{k}_loss_{e}"]).max() < 2e-4, (tag, e, k, np.abs(got - fx[f"{k}_loss_{e}"]).max())
+    sd = {k: v.cpu().numpy() for k, v in tr.nn_twin.state_dict().items()}
+    assert np.abs(sd["fc1.weight"][:64] - fx["fc1_weight"]).max() < 1e-4
+    assert np.abs(sd["fc_value.weight"] - fx["fc_value_weight"]).max() < 1e-4
+
+
 def _dist_trainer_worker(rank, world, port, tmp, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")

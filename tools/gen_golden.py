@@ -11,6 +11,9 @@ the two-line shim of SURVEY.md Appendix B and records small fixtures under tests
   G4 selfplay_<game>.npz AlphaZeroTrainer.self_play memory (samples before/after normalise and
                          after the symmetry augmentation) under the same patches
   G5 stats.npz           outcome statistics of reference rollout-MCTS TicTacToe self-play
+  G6 sgd_<game>.npz      AlphaZeroTrainer.optimize_network (trainer.py:320-381): per-batch policy / value losses of two
+                         epochs on the G4 memory and the trained fc1 / value-head weights (closed-form initial weights,
+                         dropout 0, np.random.seed pinned for the batch shuffle)
 
 The fixtures hold data only (inputs and expected outputs).  Usage: python tools/gen_golden.py [names]
 """
@@ -367,6 +370,48 @@ def gen_selfplay(R, tag, episodes, sims, seed=7):
     print(f"selfplay_{tag}: {n_orig} samples (+{len(mem) - n_orig} augmented), transformations={transf}")
 
 
+# ------------------------------------------------------------------------------------------- G6
+SGD_PLAN = {"tictactoe": dict(batch_size=16, epochs=2, shuffle_seed=4242), "connect4": dict(batch_size=32, epochs=2, shuffle_seed=4243),
+            "othello6": dict(batch_size=32, epochs=2, shuffle_seed=4244)}
+
+
+def gen_sgd(R, tag):
+    """the reference's optimisation loop on the committed G4 memory; everything random is pinned"""
+    import torch
+    torch.set_num_threads(1)
+    game, kw, A, n = GAMES[tag]
+    plan = SGD_PLAN[tag]
+    fx = np.load(os.path.join(GOLD, f"selfplay_{tag}.npz"), allow_pickle=False)
+    T = R.trainer
+    extra = {"board_size": n} if game == "othello" else {}
+    cfg = R.registers.CONFIGS_REGISTER[game](epochs=plan["epochs"], batch_size=plan["batch_size"], **extra)
+    tr = T.AlphaZeroTrainer(verbose=False)
+    tr.config, tr.game = cfg, game
+    tr.board = R.registers.BOARDS_REGISTER[game](config=cfg)
+    net = make_net(R, tag)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.tensor(v) for k, v in cf.closed_form_state_dict(shapes).items()})
+    if hasattr(net, "dropout"):
+        net.dropout = 0.0  # the only unpinnable randomness of the step (torch's dropout mask)
+    tr.nn = net
+    tr.memory = [T.Sample(state=fx["state"][i].astype(np.float64), pi=fx["pi"][i].copy(), player=1, outcome=int(fx["outcome"][i]),
+                          episode_idx=int(fx["episode_idx"][i]), move_idx=int(fx["move_idx"][i])) for i in range(len(fx["outcome"]))]
+    tr.loss_values = {}
+    np.random.seed(plan["shuffle_seed"])
+    tr.optimize_network(0)
+    sd = tr.nn_twin.state_dict()
+    out = {"batch_size": np.int32(plan["batch_size"]), "epochs": np.int32(plan["epochs"]), "shuffle_seed": np.int32(plan["shuffle_seed"]),
+           "n_samples": np.int32(len(tr.memory)), "lr": np.float64(cfg.learning_rate),
+           "fc1_weight": sd["fc1.weight"].numpy().astype(np.float32)[:64], "fc_value_weight": sd["fc_value.weight"].numpy().astype(np.float32),
+           "bn_running_mean": sd[("fc_bn1" if game != "tictactoe" else "bn1") + ".running_mean"].numpy().astype(np.float32)}
+    for e in range(plan["epochs"]):
+        out[f"pi_loss_{e}"] = np.array(tr.loss_values[0][e]["pi"], np.float64)
+        out[f"v_loss_{e}"] = np.array(tr.loss_values[0][e]["v"], np.float64)
+    np.savez_compressed(os.path.join(GOLD, f"sgd_{tag}.npz"), **out)
+    print(f"sgd_{tag}: {len(tr.memory)} samples, {len(out['pi_loss_0'])} steps/epoch, first losses pi={out['pi_loss_0'][0]:.6f} v={out['v_loss_0'][0]:.6f}, "
+          f"last pi={out['pi_loss_%d' % (plan['epochs'] - 1)][-1]:.6f}")
+
+
 # ------------------------------------------------------------------------------------------- G5
 def gen_stats(R):
     """BASELINE config 1: TicTacToe, MCTSPlayer(n_sim=100) rollout mode, temp 0, self-play outcome mix."""
@@ -407,6 +452,9 @@ def main():
             gen_selfplay(R, tag, *sp[tag])
     if not want or "stats" in want:
         gen_stats(R)
+    for tag in SGD_PLAN:
+        if not want or "sgd" in want or f"sgd_{tag}" in want:
+            gen_sgd(R, tag)
 
 
 if __name__ == "__main__":
