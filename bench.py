@@ -4,16 +4,24 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is `--waves` (1) self-play wave(s): every rank keeps `--games` (32768) Othello 8x8 games resident and
-plays waves x games of them from the start position to the end at 100 MCTS simulations per move through the
-HIP engine (finished slots are refilled at once)
-(random-init OthelloNet(n=8) under torch.manual_seed(0), Dirichlet noise 0.03/0.25, tau linear(4,4),
-tree reuse) and, for N > 1, all-gathers the samples over RCCL.  value = games of all ranks / time.
+A "step" is one self-play wave: every rank keeps `--games` Othello 8x8 games resident and plays them from the start
+position to the end at 100 MCTS simulations per move through the HIP engine (random-init OthelloNet(n=8) under
+torch.manual_seed(0), Dirichlet noise 0.03/0.25, tau linear(4,4), tree reuse) and, for N > 1, all-gathers the samples over
+RCCL.  value = games of all ranks / time.  The timed region runs the engine as it ships (searches replayed as HIP
+graphs, no event recording); the per-kernel times of the roofline come from one extra, separately profiled step.
+
+At N = 1 the same JSON line also carries the two single-GPU BASELINE configs at their LITERAL sizes:
+  config2 : Othello 8x8, 4096 concurrent games, 100 sims/move           (BASELINE.json configs[1])
+  config4 : Connect4 6x7, 8192 concurrent games, 200 sims/move          (BASELINE.json configs[3])
+each with games/s, examples/s and its own roofline object, and `cpu_baseline`: the CPU oracle (C port of the
+reference's self-play loop) timed on the host cores with the protocol of BASELINE.md section 3.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,26 +33,192 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
-STAGE_NAMES = ["k_trunk2 (conv1-4)", "k_gemm fc1", "k_gemm fc2", "k_heads"]
+PROF_NAMES = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads"]
+# the Python reference and the C oracle on ONE core of the build container (Xeon @ 2.10 GHz, 8 vCPU): BASELINE.md section 2
+# (8.38 s per Othello 8x8 game at 100 sims) and `python oracle/selfplay_worker.py` there (4 games: 6.33 +- 0.73 s per game)
+REF_S_PER_GAME_BUILD_CONTAINER = 8.38
+ORACLE_S_PER_GAME_BUILD_CONTAINER = 6.33
 
 
-def stage_flops(n):
-    conv = 2 * (n * n * 9 * 32 + n * n * 9 * 32 * 32 + (n - 2) ** 2 * 9 * 32 * 32 + (n - 4) ** 2 * 9 * 32 * 32)
-    fin = 32 * (n - 4) ** 2
-    return [conv, 2 * fin * 1024, 2 * 1024 * 512, 2 * 512 * (n * n + 2)]
+def stage_flops(CH, CW, F1, F2, A):
+    """algorithmic FLOPs (2 x MAC) per board of the four network stages"""
+    p1, p3, p4 = CH * CW, (CH - 2) * (CW - 2), (CH - 4) * (CW - 4)
+    conv = 2 * (p1 * 9 * 32 + p1 * 9 * 32 * 32 + p3 * 9 * 32 * 32 + p4 * 9 * 32 * 32)
+    return [conv, 2 * 32 * p4 * F1, 2 * F1 * F2, 2 * F2 * (A + 1)]
 
 
-def cpu_baseline(state_dict, n_games=6, n_sim=100):
-    """the CPU oracle (C port of the reference's self-play loop) on one host core, same weights/config"""
+def algorithmic_bytes(CH, CW, F1, F2, A):
+    """algorithmic HBM bytes per board of the four network stages (inputs + outputs; weights stay cache resident)"""
+    fin = 32 * (CH - 4) * (CW - 4)
+    return [4 * (CH * CW + fin), 4 * (fin + F1), 4 * (F1 + F2), 4 * (F2 + A + 1)]
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(state_dict, n_sim=100, games_per_proc=3):
+    """BASELINE.md section 3 on this box's host cores, with the CPU oracle (the checker; C port of the reference's loop):
+    one process, then one process per core (<= 16), >= 3 games each, every game timed (SelfPlayTimer idiom,
+    timers.py:53-76); then the Arena path (AlphaZeroPlayer @100 vs rollout MCTSPlayer @100, 2 rounds, arena.py:119-185).
+    Runs BEFORE this process touches the GPU: the workers are plain child processes that never see HIP."""
     from oracle import oracle as O
-    net = O.ConvNet(O.OTHELLO, 8, 8, {k: v.cpu().numpy() for k, v in state_dict.items() if not k.endswith("num_batches_tracked")})
+    from oracle import selfplay_worker as W
+    weights = {k: v.cpu().numpy() for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+    t_all = time.perf_counter()
+    one = W.play(weights, games_per_proc, n_sim, 0)
+    s1 = np.array(one["seconds_per_game"])
+    nproc = max(1, min(os.cpu_count() or 1, 16))
+    many = None
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "w.npz")
+        np.savez(path, **weights)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "selfplay_worker.py"), path, str(games_per_proc),
+                                   str(n_sim), str(1000 * (i + 1))], stdout=subprocess.PIPE, text=True,
+                                  env=dict(os.environ, OMP_NUM_THREADS="1")) for i in range(nproc)]
+        outs = [p.communicate()[0] for p in procs]
+        wall = time.perf_counter() - t0
+        if all(p.returncode == 0 for p in procs):
+            per = np.concatenate([json.loads(o.strip().splitlines()[-1])["seconds_per_game"] for o in outs])
+            plies = sum(json.loads(o.strip().splitlines()[-1])["plies"] for o in outs)
+            many = {"processes": nproc, "games": int(len(per)), "wall_s": wall, "games_per_sec": len(per) / wall, "examples_per_sec": plies / wall,
+                    "s_per_game_mean": float(per.mean()), "s_per_game_std": float(per.std())}
+    net = O.ConvNet(O.OTHELLO, 8, 8, weights)
     t0 = time.perf_counter()
-    r = O.selfplay(O.OTHELLO, 8, 8, n_games, n_sim, ("conv", net), seed=0)
+    moves, winners, _, _ = O.arena_games((O.OTHELLO, 8, 8), ("conv", net), n_sim, "mcts", n_sim, seed=0, n_rounds=2)
+    t_arena = time.perf_counter() - t0
+    return {"value": 1.0 / float(s1.mean()), "unit": "games/s", "cores": 1, "kind": "port",
+            "sample": f"{games_per_proc} full Othello 8x8 self-play games at {n_sim} sims/move ({one['plies']} plies, {one['net_evals']} net evals) "
+                      f"on 1 host core, oracle/liboracle.so; then {nproc} processes x {games_per_proc} games; then 2 Arena rounds",
+            "cpu_model": cpu_model(), "nproc": os.cpu_count(),
+            "one_process": {"games": games_per_proc, "s_per_game_mean": float(s1.mean()), "s_per_game_std": float(s1.std()),
+                            "games_per_sec": 1.0 / float(s1.mean()), "examples_per_sec": one["plies"] / float(s1.sum())},
+            "all_cores": many,
+            "arena": {"rounds": 2, "player1": f"AlphaZeroPlayer({n_sim} sims)", "player2": f"MCTSPlayer(rollout, {n_sim} sims)",
+                      "seconds": t_arena, "s_per_game": t_arena / 2, "plies": [len(m) for m in moves], "winners": winners},
+            "reference_python": {"s_per_game": REF_S_PER_GAME_BUILD_CONTAINER, "games_per_sec": 1.0 / REF_S_PER_GAME_BUILD_CONTAINER,
+                                 "where": "build container, Xeon @ 2.10 GHz, 1 core (BASELINE.md section 2)",
+                                 "oracle_s_per_game_same_core": ORACLE_S_PER_GAME_BUILD_CONTAINER,
+                                 "oracle_speedup_over_reference_same_core": REF_S_PER_GAME_BUILD_CONTAINER / ORACLE_S_PER_GAME_BUILD_CONTAINER},
+            "seconds": time.perf_counter() - t_all}
+
+
+# ------------------------------------------------------------------------------------------------ one workload
+class Workload:
+    """one BASELINE config on this rank's GPU: engine + network + the bookkeeping of the roofline"""
+
+    def __init__(self, name, game, G, sims, seed=0):
+        from alphazero_amd import engine as E
+        from alphazero_amd.games.connect4 import Connect4Net
+        from alphazero_amd.games.othello import OthelloNet
+        self.name, self.game, self.G, self.sims = name, game, G, sims
+        torch.manual_seed(0)
+        if game == "othello":
+            self.gid, self.H, self.W, self.model = 0, 8, 8, OthelloNet(n=8).eval()
+            self.geom = (8, 8, 1024, 512, 65)
+            self.desc = f"Othello 8x8, {G} concurrent self-play games per GPU, {sims} sims/move, random-init OthelloNet(n=8) seed 0"
+        else:
+            self.gid, self.H, self.W, self.model = 1, 6, 7, Connect4Net(7, 6).eval()
+            self.geom = (7, 6, 64, 32, 7)  # the (6,7) grid is view-ed as a 7x6 plane (connect4.py:399)
+            self.desc = f"Connect4 6x7, {G} concurrent self-play games per GPU, {sims} sims/move, random-init Connect4Net(7,6) seed 0"
+        self.desc += ", Dirichlet 0.03/0.25, tau linear(4,4), tree reuse"
+        self.hnet = self.model.to_hip(max_batch=G)
+        plies = 128 if game == "othello" else 43
+        self.eng = E.SelfPlayEngine(self.gid, self.H, self.W, n_slots=G, n_sim=sims, net=self.hnet, dirichlet_alpha=0.03,
+                                    dirichlet_epsilon=0.25, temp_max_step=4, temp_min_step=4, tie_mode=E.TIE_RANDOM,
+                                    noise_mode=E.NOISE_PHILOX, seed=seed, max_plies=plies, sample_capacity=G * (72 if game == "othello" else 43))
+
+    def wave(self, first_game_id):
+        """one step on this rank: G games to the end; returns (samples dict of device views, engine stats)"""
+        self.eng.run(self.G, first_game_id=first_game_id)
+        return self.eng.samples(copy=False), self.eng.stats()
+
+    def profiled_wave(self, first_game_id):
+        """one more step with HIP events around every network kernel launch (az_net_profile; kernel-by-kernel launches
+        instead of graph replays).  -> roofline object of the dominant kernel + the step's time split"""
+        self.hnet.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, st = self.wave(first_game_id)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = self.hnet.profile_read()
+        self.hnet.profile(False)
+        fl, by = stage_flops(*self.geom), algorithmic_bytes(*self.geom)
+        evals = st["net_evals"]
+        tot_ms = [prof[k][0] for k in PROF_NAMES]
+        tot_ms[0] += prof["k_trunk"][0]  # small-batch launches of the one-board-per-wave trunk kernel
+        launches = [prof[k][1] for k in PROF_NAMES]
+        launches[0] += prof["k_trunk"][1]
+        dom = int(np.argmax(tot_ms))
+        ach = fl[dom] * evals / (tot_ms[dom] * 1e-3) / 1e12
+        key = f"{self.game}_{self.G}"
+        traffic, counters = None, None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per full-batch launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tfile):
+            t = json.load(open(tfile)).get(key)
+            if t:
+                traffic = t.get(["k_trunk", "k_gemm_fc1", "k_gemm_fc2", "k_heads"][dom])
+        cfile = os.path.join(ROOT, "profiles", "mfma_counters.json")  # SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES passes
+        if os.path.exists(cfile):
+            counters = json.load(open(cfile)).get(key)
+        full = [self.hnet.time_stage(s, self.G, iters=20) for s in range(4)]
+        net_ms = sum(tot_ms)
+        roof = {"bound": "mfma", "kernel": PROF_NAMES[dom] + (" (+k_trunk at small batches)" if dom == 0 and prof["k_trunk"][1] else ""),
+                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic,
+                "traffic_is_for": f"one launch at the full batch of {self.G} boards (tools/prof_net.py under rocprofv3 --pmc); algorithmic bytes of that launch: {self.G * by[dom]}",
+                "mfma_busy": (counters or {}).get(["k_trunk", "k_gemm_fc1", "k_gemm_fc2", "k_heads"][dom]),
+                "launches": launches[dom], "avg_launch_ms": tot_ms[dom] / max(1, launches[dom]),
+                "avg_boards_per_launch": evals / max(1, launches[dom]),
+                "algorithmic_flops_per_board": fl[dom], "boards_evaluated": evals,
+                "measured_on": "one separately profiled step after the timed region (HIP events on the engine's stream around every launch)",
+                "profiled_step_ms": 1e3 * dt,
+                "profiled_step_kernel_ms": {k: prof[k][0] for k in prof}, "profiled_step_launches": {k: prof[k][1] for k in prof},
+                "stage_tflops": {PROF_NAMES[i]: (fl[i] * evals / (tot_ms[i] * 1e-3) / 1e12 if tot_ms[i] > 0 else None) for i in range(4)},
+                "full_batch_launch_ms": dict(zip(PROF_NAMES, full)),
+                "full_batch_tflops": {PROF_NAMES[i]: fl[i] * self.G / (full[i] * 1e-3) / 1e12 for i in range(4)},
+                "forward_tflops": sum(fl) * evals / (net_ms * 1e-3) / 1e12,
+                "network_share_of_step": net_ms / (1e3 * dt),
+                "tree_and_host_share_of_step": 1.0 - net_ms / (1e3 * dt)}
+        return roof
+
+    def close(self):
+        self.eng.close()
+        self.hnet.close()
+
+
+def run_single(name, game, G, sims, steps, warmup):
+    """a BASELINE config at its literal size on one GPU: `steps` timed waves (graphs on, no profiling) + one profiled wave"""
+    w = Workload(name, game, G, sims)
+    for i in range(warmup):
+        w.wave(i * G)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_samples, evals = 0, 0
+    for k in range(steps):
+        smp, st = w.wave((warmup + k) * G)
+        n_samples += smp["z"].shape[0]
+        evals += st["net_evals"]
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"value": n_games / dt, "unit": "games/s", "cores": 1, "kind": "port",
-            "sample": f"{n_games} full Othello 8x8 self-play games at {n_sim} sims/move ({len(r['z'])} plies, "
-                      f"{r['n_evals']} net evals) on 1 host core, oracle/liboracle.so",
-            "examples_per_sec": len(r["z"]) / dt, "seconds": dt}
+    st = w.eng.stats()
+    games = steps * G
+    out = {"workload": w.desc, "value": games / dt, "unit": "games/s", "examples_per_sec": n_samples / dt, "sims_per_sec": n_samples * sims / dt,
+           "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "plies_per_game": n_samples / games,
+           "net_evals_per_step": evals / steps, "lockstep_iters_last_step": st["lockstep_iters"], "graph_replays": st["graph_replays"],
+           "max_tree_nodes_per_game": st["max_nodes_used"], "dtype": "f32"}
+    out["roofline"] = w.profiled_wave((warmup + steps) * G)
+    w.close()
+    return out
 
 
 def main():
@@ -52,11 +226,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=32768, help="concurrent games (engine slots) per GPU")
-    ap.add_argument("--waves", type=int, default=1, help="games per step per GPU = waves x games; finished slots are refilled, "
-                                                           "so the ragged end of a wave (games last 60-65 plies) overlaps the next")
+    ap.add_argument("--games", type=int, default=32768, help="concurrent games (engine slots) per GPU of the headline run")
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-literal-configs", action="store_true", help="skip the config2 / config4 objects (N = 1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,6 +237,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:  # before HIP is initialised: the worker processes are forked from a GPU-free parent
+        from alphazero_amd.games.othello import OthelloNet
+        torch.manual_seed(0)
+        cpu = cpu_baseline(OthelloNet(n=8).eval().state_dict())
+
     # AZ_BENCH_BACKEND=gloo + AZ_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 control flow on a one-GPU box
     backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
     if os.environ.get("AZ_BENCH_ONE_DEVICE") == "1":
@@ -75,17 +255,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from alphazero_amd import engine as E
     from alphazero_amd.dist import all_gather_samples, rank_game_range
-    from alphazero_amd.games.othello import OthelloNet
 
-    n, G = 8, args.games
-    torch.manual_seed(0)
-    model = OthelloNet(n=n).eval()
-    hnet = model.to_hip(max_batch=G)
-    eng = E.SelfPlayEngine(0, n, n, n_slots=G, n_sim=args.sims, net=hnet, dirichlet_alpha=0.03, dirichlet_epsilon=0.25,
-                           temp_max_step=4, temp_min_step=4, tie_mode=E.TIE_RANDOM, noise_mode=E.NOISE_PHILOX,
-                           seed=0, max_plies=128, sample_capacity=args.waves * G * 72)
+    G = args.games
+    w = Workload("headline", "othello", G, args.sims)
+    gather_s = [0.0]
 
     def sync():
         torch.cuda.synchronize()
@@ -94,79 +268,76 @@ def main():
             torch.cuda.synchronize()
 
     def step(wave):
-        first, cnt = rank_game_range(rank, world, args.waves * G, wave)
-        eng.run(cnt, first_game_id=first)
-        smp = eng.samples(copy=False)
+        first, cnt = rank_game_range(rank, world, G, wave)
+        smp, st = w.wave(first)
         if world > 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             smp = all_gather_samples({k: smp[k] for k in ("state", "pi", "z", "meta")})
-        return smp["z"].shape[0]
+            torch.cuda.synchronize()
+            gather_s[0] += time.perf_counter() - t0
+        return smp["z"].shape[0], st["net_evals"]
 
-    for w in range(args.warmup):
-        step(w)
-    if rank == 0:
-        hnet.profile(True)  # HIP events around every network kernel launch of the timed region (engine's stream)
+    for i in range(args.warmup):
+        step(i)
+    gather_s[0] = 0.0
     sync()
     t0 = time.perf_counter()
     n_samples_total, evals_total = 0, 0
     for k in range(args.steps):
-        n_samples_total += step(args.warmup + k)
-        evals_total += eng.stats()["net_evals"]
+        s, e = step(args.warmup + k)
+        n_samples_total += s
+        evals_total += e
+    t_local = time.perf_counter() - t0  # this rank's own time, before it waits for the others
     sync()
     dt = time.perf_counter() - t0
-    prof = hnet.profile_read() if rank == 0 else None
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = torch.tensor([t_local, gather_s[0]], dtype=torch.float64, device=dev)
+    per_rank_all = per_rank.clone().view(1, 2)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank_all = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(per_rank_all, per_rank)
     dt = float(t.item())
-    st = eng.stats()
+    per_rank_all = per_rank_all.cpu().numpy()
+    st = w.eng.stats()
 
     if rank == 0:
-        games = args.steps * args.waves * G * world
+        games = args.steps * G * world
         samples = n_samples_total  # after the all-gather every rank holds all ranks' samples
         out = {
             "metric": "self-play games/sec (whole node), Othello 8x8 @100 sims/move", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Othello 8x8, {G} concurrent self-play games per GPU, {args.sims} sims/move, "
-                                   f"random-init OthelloNet(n=8) seed 0, Dirichlet 0.03/0.25, tau linear(4,4), tree reuse",
-                       "games_per_gpu_per_step": args.waves * G, "concurrent_games_per_gpu": G, "sims_per_move": args.sims,
-                       "parallelism": f"game-sharded x{world}"},
+            "config": {"workload": w.desc, "games_per_gpu_per_step": G, "concurrent_games_per_gpu": G, "sims_per_move": args.sims,
+                       "parallelism": f"game-sharded x{world}", "timed_region": "engine as shipped: searches replayed as HIP graphs, no event recording"},
             "examples_per_sec": samples / dt, "sims_per_sec": samples * args.sims / dt,
             "plies_per_game": samples / games, "net_evals_last_step": st["net_evals"], "lockstep_iters_last_step": st["lockstep_iters"],
-            "max_tree_nodes_per_game": st["max_nodes_used"],
+            "graph_replays": st["graph_replays"], "max_tree_nodes_per_game": st["max_nodes_used"],
+            # diagnosis of a scaling run: every rank's own step time (before waiting for the others) and its share spent in the RCCL gather
+            "per_rank_ms_per_step": [1e3 * float(x) / args.steps for x in per_rank_all[:, 0]],
+            "per_rank_gather_ms_per_step": [1e3 * float(x) / args.steps for x in per_rank_all[:, 1]],
         }
-        # roofline of the dominant kernel, measured live over the timed region: algorithmic FLOPs of the boards the
-        # network evaluated there / the time its launches took (HIP events on the engine's stream, az_net_profile)
-        fl = stage_flops(n)
-        names = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads"]
-        tot_ms = [prof[k][0] for k in names]
-        tot_ms[0] += prof["k_trunk"][0]  # the few small-batch launches of the one-board-per-wave trunk kernel
-        dom = int(np.argmax(tot_ms))
-        ach = fl[dom] * evals_total / (tot_ms[dom] * 1e-3) / 1e12
-        kname = names[dom]
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per full-batch launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tfile) and json.load(open(tfile)).get("batch") == G:
-            traffic = json.load(open(tfile)).get(["k_trunk", "k_gemm_fc1", "k_gemm_fc2", "k_heads"][dom])
-        full = [hnet.time_stage(s, G, iters=20) for s in range(4)]  # context: one launch at the full batch
-        out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "traffic_is_for": f"one launch at the full batch of {G} boards (PMC passes run tools/prof_net.py); "
-                                             f"algorithmic bytes of that launch: {G * (n * n * 4 + 32 * (n - 4) ** 2 * 4)}",
-                           "launches": prof[kname][1], "avg_launch_ms": prof[kname][0] / max(1, prof[kname][1]),
-                           "avg_boards_per_launch": evals_total / max(1, prof[kname][1] + (prof["k_trunk"][1] if dom == 0 else 0)),
-                           "algorithmic_flops_per_board": fl[dom], "boards_evaluated": evals_total,
-                           "timed_region_ms": {k: prof[k][0] for k in prof}, "timed_region_launches": {k: prof[k][1] for k in prof},
-                           "full_batch_launch_ms": dict(zip(STAGE_NAMES, full)),
-                           "full_batch_tflops": {STAGE_NAMES[i]: fl[i] * G / (full[i] * 1e-3) / 1e12 for i in range(4)},
-                           "forward_tflops": sum(fl) * evals_total / (sum(tot_ms) * 1e-3) / 1e12}
-        # the tree kernels' side of SURVEY 8d: algorithmic HBM bytes of select / expand / backup per simulation
+    if world > 1:
+        dist.barrier()
+    # the roofline's per-kernel times: one extra step, profiled, outside the timed region (rank 0; the others idle at the barrier)
+    roof = w.profiled_wave((args.warmup + args.steps) * G * world + rank * G) if rank == 0 else None
+    w.close()
+    if rank == 0:
+        out["roofline"] = roof
         sims_per_gpu = samples * args.sims / dt / world
-        out["tree_hbm"] = {"algorithmic_bytes_per_sim": 919, "achieved": sims_per_gpu * 919 / 1e9, "peak": 8000.0, "unit": "GB/s",
-                           "frac": sims_per_gpu * 919 / 8e12,
-                           "note": "per GPU; k_step takes 4-5 % of a step, the path is bound by the network's MFMA work"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model.state_dict())
+        tree = {"algorithmic_bytes_per_sim": 919, "achieved": sims_per_gpu * 919 / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": sims_per_gpu * 919 / 8e12, "note": "per GPU, whole path: the tree kernels are a few % of a step, the path is bound by the network's MFMA work"}
+        kfile = os.path.join(ROOT, "profiles", "kstep_counters.json")  # k_step<true,true>: duration + FETCH_SIZE / WRITE_SIZE passes (tools/refresh_profiles.sh)
+        if os.path.exists(kfile):
+            tree["k_step"] = json.load(open(kfile)).get(f"othello_{G}")
+        out["tree_hbm"] = tree
+        if world == 1 and not args.no_literal_configs:
+            out["config2"] = run_single("config2", "othello", 4096, 100, steps=3, warmup=1)
+            out["config4"] = run_single("config4", "connect4", 8192, 200, steps=3, warmup=1)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

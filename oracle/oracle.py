@@ -354,3 +354,57 @@ def random_positions(game_id, H, W, seed, n_games, cap):
     n = lib().orc_random_positions(game_id, H, W, seed, n_games, cap, grids.ctypes.data, players.ctypes.data,
                                    actions.ctypes.data)
     return grids[:n], players[:n], actions[:n]
+
+
+def arena_games(dims, ev1, n_sim, opponent, opp_sim, seed, n_rounds, start_player=None):
+    """Arena.play_games (arena.py:36-185) restated on the oracle: player 1 is an AlphaZero tree (evaluator ev1, no noise,
+    temperature 0: what AlphaZeroTrainer.evaluate builds, trainer.py:421-425); `opponent` is "random" / "greedy"
+    (players.py:76-123), "mcts" (rollout MCTSPlayer) or another evaluator tuple.  Each side owns a tree and BOTH trees
+    receive every move (arena.py:98-99).  Returns (moves per game, winners, scores, stats dict of arena.py:141-147)."""
+    from collections import defaultdict
+    gid, H, W = dims
+    p2_starts = [{1: False, 2: True}.get(start_player, bool(r % 2)) for r in range(n_rounds)]
+    all_moves, winners, scores = [], [], []
+    for r in range(n_rounds):
+        side1 = -1 if p2_starts[r] else 1
+        game_id = (r + seed * 100003) & 0xFFFFFFFF
+        t1 = MCT(ev1, eval_method=EVAL_NEURAL, tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed, game_id=game_id)
+        t2 = None
+        if opponent == "mcts":
+            t2 = MCT(("fake", None), eval_method=EVAL_ROLLOUT, tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed + 1, game_id=game_id)
+        elif not isinstance(opponent, str):
+            t2 = MCT(opponent, eval_method=EVAL_NEURAL, tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed + 1, game_id=game_id)
+        b = new_board(gid, H, W)
+        ply, moves = 0, []
+        while not lib().orc_is_over(C.byref(b)):
+            mine = b.player == side1
+            if mine or t2 is not None:
+                t, ns = (t1, n_sim) if mine else (t2, opp_sim)
+                t.set_ply(ply)
+                t.search(b, ns)
+                a = t.choose(b, 0.0)[0]
+            else:
+                a = baseline_move(b, opponent, seed + 7, game_id, ply)
+            if lib().orc_play(C.byref(b), a) != 0:
+                raise RuntimeError("oracle arena: illegal move")
+            t1.change_root(a)
+            if t2 is not None:
+                t2.change_root(a)
+            moves.append(a)
+            ply += 1
+        w = C.c_int()
+        lib().orc_winner(C.byref(b), C.byref(w))
+        sc = abs(lib().orc_score(C.byref(b)))
+        all_moves.append(moves); winners.append(w.value)
+        scores.append(float("inf") if gid == TICTACTOE and sc == 32767 else sc)
+    stats = {"player1": [], "player2": [], "draw": 0, "player1_starts": defaultdict(int), "player2_starts": defaultdict(int)}
+    for r in range(n_rounds):
+        starter = f"player{2 if p2_starts[r] else 1}_starts"
+        if winners[r] == 0:
+            stats["draw"] += 1
+            stats[starter]["draw"] += 1
+        else:
+            who = 1 if winners[r] == (-1 if p2_starts[r] else 1) else 2
+            stats[f"player{who}"].append(scores[r])
+            stats[starter]["win" if who == (2 if p2_starts[r] else 1) else "loss"] += 1
+    return all_moves, winners, scores, stats

@@ -3,9 +3,6 @@ is replayed by the CPU oracle driven exactly as Arena.play_game drives its playe
 receive every move (arena.py:98-99), the AlphaZero side searches without noise at temperature 0 (trainer.py:421-425),
 the opponent is RandomPlayer / GreedyPlayer (players.py:76-123), rollout MCTSPlayer, or another network -- and must
 produce the same move at every ply, the same winners and the same stats dict."""
-import ctypes as C
-from collections import defaultdict
-
 import numpy as np
 import pytest
 import torch
@@ -35,53 +32,7 @@ def _nets(game, seed):
     return net, ("mlp", O.MlpNet(_np_sd(net))), (O.TICTACTOE, 3, 3)
 
 
-def oracle_arena(dims, ev1, n_sim, opponent, opp_sim, seed, n_rounds, start_player=None):
-    """Arena.play_games restated on the oracle; returns (moves per game, winners, scores, stats dict)"""
-    gid, H, W = dims
-    p2_starts = [{1: False, 2: True}.get(start_player, bool(r % 2)) for r in range(n_rounds)]
-    all_moves, winners, scores = [], [], []
-    for r in range(n_rounds):
-        side1 = -1 if p2_starts[r] else 1
-        game_id = (r + seed * 100003) & 0xFFFFFFFF
-        t1 = O.MCT(ev1, eval_method=O.EVAL_NEURAL, tie_mode=O.TIE_RANDOM, noise_mode=O.NOISE_OFF, seed=seed, game_id=game_id)
-        t2 = None
-        if opponent == "mcts":
-            t2 = O.MCT(("fake", None), eval_method=O.EVAL_ROLLOUT, tie_mode=O.TIE_RANDOM, noise_mode=O.NOISE_OFF, seed=seed + 1, game_id=game_id)
-        elif not isinstance(opponent, str):
-            t2 = O.MCT(opponent, eval_method=O.EVAL_NEURAL, tie_mode=O.TIE_RANDOM, noise_mode=O.NOISE_OFF, seed=seed + 1, game_id=game_id)
-        b = O.new_board(gid, H, W)
-        ply, moves = 0, []
-        while not O.lib().orc_is_over(C.byref(b)):
-            mine = b.player == side1
-            if mine or t2 is not None:
-                t, ns = (t1, n_sim) if mine else (t2, opp_sim)
-                t.set_ply(ply)
-                t.search(b, ns)
-                a = t.choose(b, 0.0)[0]
-            else:
-                a = O.baseline_move(b, opponent, seed + 7, game_id, ply)
-            assert O.lib().orc_play(C.byref(b), a) == 0
-            t1.change_root(a)           # arena.py:98-99: both players are told every move
-            if t2 is not None:
-                t2.change_root(a)
-            moves.append(a)
-            ply += 1
-        w = C.c_int()
-        O.lib().orc_winner(C.byref(b), C.byref(w))
-        all_moves.append(moves); winners.append(w.value)
-        sc = abs(O.lib().orc_score(C.byref(b)))
-        scores.append(float("inf") if gid == O.TICTACTOE and sc == 32767 else sc)
-    stats = {"player1": [], "player2": [], "draw": 0, "player1_starts": defaultdict(int), "player2_starts": defaultdict(int)}
-    for r in range(n_rounds):
-        starter = f"player{2 if p2_starts[r] else 1}_starts"
-        if winners[r] == 0:
-            stats["draw"] += 1
-            stats[starter]["draw"] += 1
-        else:
-            who = 1 if winners[r] == (-1 if p2_starts[r] else 1) else 2
-            stats[f"player{who}"].append(scores[r])
-            stats[starter]["win" if who == (2 if p2_starts[r] else 1) else "loss"] += 1
-    return all_moves, winners, scores, stats
+oracle_arena = O.arena_games  # Arena.play_games restated on the oracle (oracle/oracle.py)
 
 
 def _check(game, opponent_kind, n_rounds, n_sim, opp_sim, seed):

@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Condenses what tools/refresh_profiles.sh wrote under gpurun_out/ into the small files kept under profiles/."""
+"""Condenses what tools/refresh_profiles.sh wrote under gpurun_out/ into the small files kept under profiles/:
+  TAG_kernel_stats.csv    rocprofv3 --stats of the bench command
+  TAG_traffic.json        HBM bytes per full-batch launch of every network kernel, per workload (FETCH_SIZE / WRITE_SIZE passes)
+  TAG_mfma_counters.json  SQ_VALU_MFMA_BUSY_CYCLES etc. per network kernel, per workload
+  TAG_kstep_counters.json k_step<true,true> inside self-play: duration, HBM bytes, wait shares
+  TAG_counters.csv        every (workload, kernel, counter) average the json files were built from"""
 import csv
 import glob
 import json
@@ -7,9 +12,11 @@ import os
 import re
 import sys
 
-tag, G = sys.argv[1], int(sys.argv[2])
+tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
+WORKLOADS = [("othello", 32768), ("othello", 4096), ("connect4", 8192)]
+FC1_KT = {"othello": "16", "connect4": "6"}  # k_gemm's last template argument KT = K / 32 of fc1 (fc2: 32 / 2)
 
 
 def find(d, suffix):
@@ -21,38 +28,96 @@ stats = find(f"{tag}_prof", "kernel_stats.csv")
 if stats:
     open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w").write(open(stats).read())
 
-def per_kernel(d, counter):
+
+def classify(name, game):
+    if "k_trunk" in name:
+        return "k_trunk"
+    if "k_heads" in name:
+        return "k_heads"
+    if "k_gemm" in name or "k_dense" in name:
+        kt = re.search(r"k_gemm<[^>]*,\s*(\d+)>", name)
+        return "k_gemm_fc1" if kt and kt.group(1) == FC1_KT[game] else "k_gemm_fc2"
+    if re.search(r"k_step<\s*true,\s*true\s*>", name) or "k_stepILb1ELb1" in name:
+        return "k_step"
+    return None
+
+
+def averages(d, game):
+    """{(kernel class, counter): (mean value, mean duration ns, dispatches)} of one counter pass"""
     f = find(d, "counter_collection.csv")
     acc = {}
     if not f:
         return acc
     for row in csv.DictReader(open(f)):
-        if row["Counter_Name"] != counter:
+        k = classify(row["Kernel_Name"], game)
+        if k is None:
             continue
-        name = row["Kernel_Name"]
-        if "k_trunk" in name:
-            k = "k_trunk"
-        elif "k_heads" in name:
-            k = "k_heads"
-        elif "k_gemm" in name:
-            kt = re.search(r"k_gemm<[^>]*,\s*(\d+)>", name)  # last template argument KT = K / 32: 16 -> fc1 (K=512), 32 -> fc2
-            k = "k_gemm_fc1" if kt and kt.group(1) == "16" else "k_gemm_fc2"
-        else:
-            continue
-        acc.setdefault(k, []).append(float(row["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+        dur = None
+        if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+            dur = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        a = acc.setdefault((k, row["Counter_Name"]), [0.0, 0.0, 0])
+        a[0] += float(row["Counter_Value"]); a[1] += dur or 0.0; a[2] += 1
+    return {k: (v[0] / v[2], v[1] / v[2], v[2]) for k, v in acc.items()}
 
 
-fetch = per_kernel(f"{tag}_pmc_fetch", "FETCH_SIZE")
-write = per_kernel(f"{tag}_pmc_write", "WRITE_SIZE")
-if fetch and write:
-    traffic = {"batch": G}
-    with open(os.path.join(out, f"{tag}_hbm_counters.csv"), "w") as fh:
-        fh.write("kernel,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
-        for k in ("k_trunk", "k_gemm_fc1", "k_gemm_fc2", "k_heads"):
-            if k in fetch and k in write:
-                b = int((2 * fetch[k] + write[k]) * 1024)  # gfx950: FETCH_SIZE counts half of a wide read (MI355X_MICROARCH.md, HBM)
-                traffic[k] = b
-                fh.write(f"{k},{fetch[k]:.1f},{write[k]:.1f},{b}\n")
+rows, traffic, mfma, kstep = [], {}, {}, {}
+for game, B in WORKLOADS:
+    key = f"{game}_{B}"
+    fetch, write = averages(f"{tag}_pmc_fetch_{game}_{B}", game), averages(f"{tag}_pmc_write_{game}_{B}", game)
+    t = {}
+    for k in ("k_trunk", "k_gemm_fc1", "k_gemm_fc2", "k_heads"):
+        if (k, "FETCH_SIZE") in fetch and (k, "WRITE_SIZE") in write:
+            f_kb, w_kb = fetch[(k, "FETCH_SIZE")][0], write[(k, "WRITE_SIZE")][0]
+            t[k] = int((2 * f_kb + w_kb) * 1024)  # gfx950: FETCH_SIZE counts half of a wide read (MI355X_MICROARCH.md, HBM)
+            rows.append((key, k, "FETCH_SIZE_KB", f_kb, fetch[(k, "FETCH_SIZE")][2])); rows.append((key, k, "WRITE_SIZE_KB", w_kb, write[(k, "WRITE_SIZE")][2]))
+    if t:
+        traffic[key] = t
+    m = {}
+    for d in (f"{tag}_pmc_mfma_{game}_{B}", f"{tag}_pmc_mops_{game}_{B}"):
+        for (k, c), (v, dur, n) in averages(d, game).items():
+            if k == "k_step":
+                continue
+            m.setdefault(k, {})[c] = v
+            if dur:
+                m[k]["duration_us_under_pmc"] = dur / 1e3
+            rows.append((key, k, c, v, n))
+    for k, c in m.items():
+        # share of the SIMD-cycles of the launch in which the matrix pipe was busy: both counters are summed over the chip's
+        # 1024 SIMDs (SQ_BUSY_CYCLES per SQ: x4 SIMDs); reported raw as well
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+            c["mfma_busy_cycles_per_gui_active_cycle"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["GRBM_GUI_ACTIVE"]
+    if m:
+        mfma[key] = m
+    ks = {}
+    for d, ctrs in ((f"{tag}_kstep_fetch_{game}_{B}", ["FETCH_SIZE"]), (f"{tag}_kstep_write_{game}_{B}", ["WRITE_SIZE"]),
+                    (f"{tag}_kstep_sq_{game}_{B}", None)):
+        for (k, c), (v, dur, n) in averages(d, game).items():
+            if k != "k_step":
+                continue
+            ks[c] = v
+            ks["launches_averaged"] = n
+            if dur:
+                ks["duration_us_under_pmc"] = dur / 1e3
+            rows.append((key, k, c, v, n))
+    if "FETCH_SIZE" in ks and "WRITE_SIZE" in ks:
+        ks["hbm_bytes_per_launch_upper"] = int((2 * ks["FETCH_SIZE"] + ks["WRITE_SIZE"]) * 1024)  # x2: calibrated for wide streams only; 16/32-byte node accesses are uncalibrated
+        ks["hbm_bytes_per_launch_lower"] = int((ks["FETCH_SIZE"] + ks["WRITE_SIZE"]) * 1024)
+        ks["algorithmic_bytes_per_launch"] = 919 * B
+    if ks.get("SQ_WAVE_CYCLES"):
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if c in ks:
+                ks[c + "_share_of_wave_cycles"] = ks[c] / ks["SQ_WAVE_CYCLES"]
+    if ks:
+        kstep[key] = ks
+if traffic:
     json.dump(traffic, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
-print("collected", tag)
+if mfma:
+    json.dump(mfma, open(os.path.join(out, f"{tag}_mfma_counters.json"), "w"), indent=1)
+if kstep:
+    json.dump(kstep, open(os.path.join(out, f"{tag}_kstep_counters.json"), "w"), indent=1)
+if rows:
+    with open(os.path.join(out, f"{tag}_counters.csv"), "w") as fh:
+        fh.write("workload,kernel,counter,mean_per_launch,launches\n")
+        for r in rows:
+            fh.write(",".join(str(x) for x in r) + "\n")
+print("collected", tag, "traffic", list(traffic), "mfma", list(mfma), "kstep", list(kstep))

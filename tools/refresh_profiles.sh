@@ -1,20 +1,39 @@
 #!/bin/bash
-# Runs on the MI355X box (gpurun): HBM counter passes, bench line, rocprofv3 kernel stats of the same command.
-# usage: tools/refresh_profiles.sh TAG [GAMES]   -> gpurun_out/TAG_*  (copy what should be judged into profiles/)
-# The counter passes come first: bench.py reads profiles/traffic.json for the roofline's `traffic` field.
-set -eo pipefail
-TAG=${1:-rXX}; G=${2:-32768}
+# Runs on the MI355X box (gpurun): counter passes, bench line, rocprofv3 kernel stats of the same command.
+# usage: tools/refresh_profiles.sh TAG   -> gpurun_out/TAG_*  (tools/collect_profiles.py condenses; copy into profiles/)
+# Counter passes first (bench.py reads profiles/traffic.json, mfma_counters.json, kstep_counters.json).  Every pass is
+# its own rocprofv3 run with --kernel-trace only (no --stats, no other trace domain), the program directly after `--`.
+set -o pipefail
+TAG=${1:-rXX}
 R=$(pwd); OUT=$R/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o k -- python $R/tools/prof_net.py $G 3 > $OUT/${TAG}_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o k -- python $R/tools/prof_net.py $G 3 > $OUT/${TAG}_pmc_write.log 2>&1
+pass() {  # name, counters, program args...
+  local name=$1 ctr=$2; shift 2
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${TAG}_$name -o k -- python3 "$@" > $OUT/${TAG}_$name.log 2>&1 || echo "pass $name failed (see $OUT/${TAG}_$name.log)"
+}
+for W in "othello 32768" "othello 4096" "connect4 8192"; do
+  set -- $W; g=$1; b=$2
+  pass pmc_fetch_${g}_$b FETCH_SIZE $R/tools/prof_net.py $g $b 3
+  pass pmc_write_${g}_$b WRITE_SIZE $R/tools/prof_net.py $g $b 3
+  pass pmc_mfma_${g}_$b "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" $R/tools/prof_net.py $g $b 3
+  pass pmc_mops_${g}_$b "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU" $R/tools/prof_net.py $g $b 3
+done
+# the tree kernel inside self-play (12 plies from the start position): bytes and where its waves wait
+for W in "othello 32768 100" "othello 4096 100" "connect4 8192 200"; do
+  set -- $W; g=$1; b=$2; s=$3
+  pass kstep_fetch_${g}_$b FETCH_SIZE $R/tools/prof_selfplay.py $g $b $s 12
+  pass kstep_write_${g}_$b WRITE_SIZE $R/tools/prof_selfplay.py $g $b $s 12
+  pass kstep_sq_${g}_$b "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $R/tools/prof_selfplay.py $g $b $s 12
+done
 cd $R
-python tools/collect_profiles.py $TAG $G
-cp $OUT/${TAG}_traffic.json profiles/traffic.json
-python bench.py --steps 2 --warmup 1 --games $G > $OUT/${TAG}_bench.log 2>&1
+python3 tools/collect_profiles.py $TAG
+cp $OUT/${TAG}_traffic.json profiles/traffic.json 2>/dev/null
+cp $OUT/${TAG}_mfma_counters.json profiles/mfma_counters.json 2>/dev/null
+cp $OUT/${TAG}_kstep_counters.json profiles/kstep_counters.json 2>/dev/null
+python3 bench.py > $OUT/${TAG}_bench.log 2>&1
 grep '^{' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench.json
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o k -- python $R/bench.py --steps 1 --warmup 0 --games $G --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o k -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1
 cd $R
-python tools/collect_profiles.py $TAG $G
+python3 tools/collect_profiles.py $TAG
