@@ -115,11 +115,12 @@ def cpu_baseline(state_dict, n_sim=100, games_per_proc=3):
 class Workload:
     """one BASELINE config on this rank's GPU: engine + network + the bookkeeping of the roofline"""
 
-    def __init__(self, name, game, G, sims, seed=0):
+    def __init__(self, name, game, G, sims, seed=0, waves=1):
         from alphazero_amd import engine as E
         from alphazero_amd.games.connect4 import Connect4Net
         from alphazero_amd.games.othello import OthelloNet
         self.name, self.game, self.G, self.sims = name, game, G, sims
+        self.per_step = waves * G  # games per step: G stay resident, a finished game's slot is refilled until per_step are started
         torch.manual_seed(0)
         if game == "othello":
             self.gid, self.H, self.W, self.model = 0, 8, 8, OthelloNet(n=8).eval()
@@ -130,15 +131,18 @@ class Workload:
             self.geom = (7, 6, 64, 32, 7)  # the (6,7) grid is view-ed as a 7x6 plane (connect4.py:399)
             self.desc = f"Connect4 6x7, {G} concurrent self-play games per GPU, {sims} sims/move, random-init Connect4Net(7,6) seed 0"
         self.desc += ", Dirichlet 0.03/0.25, tau linear(4,4), tree reuse"
+        if waves > 1:
+            self.desc += f"; a step plays {waves} x {G} games through the {G} resident slots (finished slots are refilled: steady state)"
         self.hnet = self.model.to_hip(max_batch=G)
         plies = 128 if game == "othello" else 43
         self.eng = E.SelfPlayEngine(self.gid, self.H, self.W, n_slots=G, n_sim=sims, net=self.hnet, dirichlet_alpha=0.03,
                                     dirichlet_epsilon=0.25, temp_max_step=4, temp_min_step=4, tie_mode=E.TIE_RANDOM,
-                                    noise_mode=E.NOISE_PHILOX, seed=seed, max_plies=plies, sample_capacity=G * (72 if game == "othello" else 43))
+                                    noise_mode=E.NOISE_PHILOX, seed=seed, max_plies=plies,
+                                    sample_capacity=self.per_step * (72 if game == "othello" else 43))
 
     def wave(self, first_game_id):
-        """one step on this rank: G games to the end; returns (samples dict of device views, engine stats)"""
-        self.eng.run(self.G, first_game_id=first_game_id)
+        """one step on this rank: per_step games to the end; returns (samples dict of device views, engine stats)"""
+        self.eng.run(self.per_step, first_game_id=first_game_id)
         return self.eng.samples(copy=False), self.eng.stats()
 
     def profiled_wave(self, first_game_id):
@@ -196,9 +200,11 @@ class Workload:
         self.hnet.close()
 
 
-def run_single(name, game, G, sims, steps, warmup):
-    """a BASELINE config at its literal size on one GPU: `steps` timed waves (graphs on, no profiling) + one profiled wave"""
-    w = Workload(name, game, G, sims)
+def run_single(name, game, G, sims, steps, warmup, waves):
+    """a BASELINE config at its literal size on one GPU (G concurrent games; SURVEY 8d: "run >= 2 waves and report the
+    steady-state rate"): `steps` timed steps of waves x G games (graphs on, no profiling) + one profiled step"""
+    w = Workload(name, game, G, sims, waves=waves)
+    G = w.per_step  # game ids advance by the games of a step
     for i in range(warmup):
         w.wave(i * G)
     torch.cuda.synchronize()
@@ -212,7 +218,7 @@ def run_single(name, game, G, sims, steps, warmup):
     dt = time.perf_counter() - t0
     st = w.eng.stats()
     games = steps * G
-    out = {"workload": w.desc, "value": games / dt, "unit": "games/s", "examples_per_sec": n_samples / dt, "sims_per_sec": n_samples * sims / dt,
+    out = {"workload": w.desc, "concurrent_games": w.G, "games_per_step": G, "value": games / dt, "unit": "games/s", "examples_per_sec": n_samples / dt, "sims_per_sec": n_samples * sims / dt,
            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "plies_per_game": n_samples / games,
            "net_evals_per_step": evals / steps, "lockstep_iters_last_step": st["lockstep_iters"], "graph_replays": st["graph_replays"],
            "max_tree_nodes_per_game": st["max_nodes_used"], "dtype": "f32"}
@@ -227,6 +233,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=32768, help="concurrent games (engine slots) per GPU of the headline run")
+    ap.add_argument("--waves", type=int, default=1, help="games per step per GPU = waves x games (finished slots are refilled)")
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal-configs", action="store_true", help="skip the config2 / config4 objects (N = 1 only)")
@@ -257,8 +264,8 @@ def main():
 
     from alphazero_amd.dist import all_gather_samples, rank_game_range
 
-    G = args.games
-    w = Workload("headline", "othello", G, args.sims)
+    w = Workload("headline", "othello", args.games, args.sims, waves=args.waves)
+    G = w.per_step
     gather_s = [0.0]
 
     def sync():
@@ -310,7 +317,7 @@ def main():
             "metric": "self-play games/sec (whole node), Othello 8x8 @100 sims/move", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": w.desc, "games_per_gpu_per_step": G, "concurrent_games_per_gpu": G, "sims_per_move": args.sims,
+            "config": {"workload": w.desc, "games_per_gpu_per_step": G, "concurrent_games_per_gpu": w.G, "sims_per_move": args.sims,
                        "parallelism": f"game-sharded x{world}", "timed_region": "engine as shipped: searches replayed as HIP graphs, no event recording"},
             "examples_per_sec": samples / dt, "sims_per_sec": samples * args.sims / dt,
             "plies_per_game": samples / games, "net_evals_last_step": st["net_evals"], "lockstep_iters_last_step": st["lockstep_iters"],
@@ -331,11 +338,11 @@ def main():
                 "frac": sims_per_gpu * 919 / 8e12, "note": "per GPU, whole path: the tree kernels are a few % of a step, the path is bound by the network's MFMA work"}
         kfile = os.path.join(ROOT, "profiles", "kstep_counters.json")  # k_step<true,true>: duration + FETCH_SIZE / WRITE_SIZE passes (tools/refresh_profiles.sh)
         if os.path.exists(kfile):
-            tree["k_step"] = json.load(open(kfile)).get(f"othello_{G}")
+            tree["k_step"] = json.load(open(kfile)).get(f"othello_{w.G}")
         out["tree_hbm"] = tree
         if world == 1 and not args.no_literal_configs:
-            out["config2"] = run_single("config2", "othello", 4096, 100, steps=3, warmup=1)
-            out["config4"] = run_single("config4", "connect4", 8192, 200, steps=3, warmup=1)
+            out["config2"] = run_single("config2", "othello", 4096, 100, steps=2, warmup=1, waves=4)
+            out["config4"] = run_single("config4", "connect4", 8192, 200, steps=2, warmup=1, waves=4)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -6,7 +6,9 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != _HERE]  # run as a script, oracle/ itself would shadow the package
+sys.path.insert(0, os.path.dirname(_HERE))
 import numpy as np  # noqa: E402
 
 from oracle import oracle as O  # noqa: E402
