@@ -1001,6 +1001,91 @@ __global__ __launch_bounds__(128) void k_heads_small(const float *__restrict__ X
     if (tid < A) probs[(size_t)m * A + tid] = e / red[0];
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_tail_small: fc1 + fc2 + heads of the SMALL conv nets (Connect4Net: 192 -> 64 -> 32 -> 7 + 1, connect4.py:382-412) in
+// one launch.  At these widths the three dense stages are 29 KFLOP per board against 1.28 MFLOP of convolutions: as three
+// kernels they cost three dependent launches of 4-6 us each (latency, not work).  Here one wavefront takes R rows through
+// all three layers without leaving its registers:
+//   fc1   lane n owns output n (F1 = 64): acc[r] = fmaf(x[r][k], W1[k][n], acc[r]) for k ascending -- x through scalar
+//         loads (wave-uniform address), W1[k][.] one coalesced 256-byte load per k shared by the R rows
+//   fc2   the k-th operand h1[r][k] sits in lane k's register: v_readlane broadcasts it (k is a compile-time constant)
+//   heads the same, lanes 0 .. NH-1; softmax over the A policy logits with the exact maximum, az_det_expf and the sum in
+//         ascending action order (as k_heads / the oracle), tanh of logit A
+// Every output is the k-ascending fmaf chain the MFMA tiles compute: bit-identical to the three-kernel path.
+// ---------------------------------------------------------------------------------------------
+AZ_D float readlane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+template <int FIN, int F1, int F2, int NH, int A, int R>
+__global__ __launch_bounds__(256) void k_tail_small(const float *__restrict__ feat, const float *__restrict__ W1, const float *__restrict__ b1,
+                                                    const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ Wh,
+                                                    const float *__restrict__ bh, int M, float *__restrict__ probs, float *__restrict__ value,
+                                                    const int *__restrict__ dyn_count) {
+    static_assert(F1 == 64 && F2 <= 64 && NH <= 64 && A < NH && FIN % 16 == 0, "one lane per fc1 output");
+    if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
+    const int lane = threadIdx.x & 63;
+    const int row0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)) * R);
+    if (row0 >= M) return;  // waves are independent: no workgroup barrier
+    int rows[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rows[r] = row0 + r < M ? row0 + r : M - 1;  // wave-uniform, in bounds
+    float acc[R];
+    {
+        const float bv = b1[lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = bv;
+    }
+    for (int k0 = 0; k0 < FIN; k0 += 16) {
+        float w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = W1[(size_t)(k0 + i) * F1 + lane];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fmaf(feat[(size_t)rows[r] * FIN + k0 + i], w[i], acc[r]);
+    }
+    float h1[R], a2[R];
+    {
+        const int n2 = lane < F2 ? lane : F2 - 1;
+        const float bv = b2[n2];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { h1[r] = acc[r] > 0.0f ? acc[r] : 0.0f; a2[r] = bv; }
+#pragma unroll
+        for (int k = 0; k < F1; ++k) {
+            const float w = W2[k * F2 + n2];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a2[r] = fmaf(readlane_f(h1[r], k), w, a2[r]);
+        }
+    }
+    float h2[R], lg[R];
+    {
+        const int j = lane < NH ? lane : NH - 1;
+        const float bv = bh[j];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { h2[r] = a2[r] > 0.0f ? a2[r] : 0.0f; lg[r] = bv; }
+#pragma unroll
+        for (int k = 0; k < F2; ++k) {
+            const float w = Wh[k * NH + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) lg[r] = fmaf(readlane_f(h2[r], k), w, lg[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float m = readlane_f(lg[r], 0);
+#pragma unroll
+        for (int a = 1; a < A; ++a) m = fmaxf(m, readlane_f(lg[r], a));
+        const float e = lane < A ? az_det_expf(lg[r] - m) : 0.0f;
+        float s = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) s += readlane_f(e, a);  // ascending action order
+        const float vl = readlane_f(lg[r], A);
+        if (row0 + r < M) {
+            if (lane < A) probs[(size_t)(row0 + r) * A + lane] = e / s;
+            if (lane == 0) value[row0 + r] = az_det_tanhf(vl);
+        }
+    }
+}
+
 template <int NT>
 constexpr int heads_lds_bytes() { return 4 * (32 * (128 + 2) + 128 * NT * 16 + 32 * (NT * 16 + 1) + 32); }
 
@@ -1529,7 +1614,23 @@ static int launch_heads(az_net *n, int B, float *probs, float *value, const int 
     }
 }
 
+// fc1 + fc2 + heads as ONE launch where the dense layers are small (Connect4Net); returns false when no instantiation fits
+static bool tail_is_fused(const az_net *n) {
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("AZ_NO_FUSED_TAIL"); off = (e && atoi(e)) ? 1 : 0; }
+    return !off && n->F1 == 64 && n->F2 == 32 && n->NH == 16 && ((n->FIN == 192 && n->A == 7) || (n->FIN == 512 && n->A == 8));
+}
+
+static int launch_tail(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
+    constexpr int R = 4;
+    const dim3 grid((unsigned)((B + 4 * R - 1) / (4 * R))), block(256);
+    if (n->FIN == 192) hipLaunchKernelGGL((k_tail_small<192, 64, 32, 16, 7, R>), grid, block, 0, st, n->feat, n->fc1w, n->fc1b, n->fc2w, n->fc2b, n->hw, n->hb, B, probs, value, dyn);
+    else hipLaunchKernelGGL((k_tail_small<512, 64, 32, 16, 8, R>), grid, block, 0, st, n->feat, n->fc1w, n->fc1b, n->fc2w, n->fc2b, n->hw, n->hb, B, probs, value, dyn);
+    return AZ_OK;
+}
+
 static int run_stage(az_net *n, int stage, const float *d_input, int B, const int *dyn, float *d_probs, float *d_value, hipStream_t st) {
+    if (stage >= 1 && tail_is_fused(n)) return stage == 1 ? launch_tail(n, B, d_probs, d_value, dyn, st) : AZ_OK;  // stages 2, 3 ran inside stage 1
     switch (stage) {
         case 0:
             if (n->CH == 8 && n->CW == 8) return launch_trunk<8, 8>(n, d_input, B, dyn, st);

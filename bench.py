@@ -341,8 +341,11 @@ def main():
             tree["k_step"] = json.load(open(kfile)).get(f"othello_{w.G}")
         out["tree_hbm"] = tree
         if world == 1 and not args.no_literal_configs:
-            out["config2"] = run_single("config2", "othello", 4096, 100, steps=2, warmup=1, waves=4)
-            out["config4"] = run_single("config4", "connect4", 8192, 200, steps=2, warmup=1, waves=4)
+            # Othello games all last 60-65 plies: one synchronised wave per step keeps 92 % of the leaf rows filled (the rest are
+            # terminal leaves, which need no evaluation).  Connect4 games last 18-42 plies: finished slots are refilled and a
+            # step plays 8 x 8192 games, so that the drain at the end of a step (its length is one game) is amortised
+            out["config2"] = run_single("config2", "othello", 4096, 100, steps=3, warmup=1, waves=1)
+            out["config4"] = run_single("config4", "connect4", 8192, 200, steps=2, warmup=1, waves=8)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
