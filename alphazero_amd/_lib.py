@@ -36,7 +36,7 @@ SYMBOLS = [
     "az_last_error", "az_version", "az_board_legal_batch", "az_board_play_batch", "az_board_status_batch",
     "az_net_create", "az_net_destroy", "az_net_set_tensor", "az_net_commit", "az_net_set_tensor_device", "az_net_commit_device", "az_net_forward", "az_net_forward_dyn",
     "az_net_action_size",
-    "az_net_flops_per_board", "az_net_time_stage", "az_net_profile", "az_net_profiling", "az_net_profile_read", "az_engine_create", "az_engine_destroy", "az_engine_run",
+    "az_net_flops_per_board", "az_net_time_stage", "az_net_profile", "az_net_profiling", "az_net_profile_read", "az_net_profile_overhead", "az_engine_create", "az_engine_destroy", "az_engine_run",
     "az_engine_get_stats", "az_engine_samples", "az_engine_set_roots", "az_engine_search", "az_engine_advance",
     "az_engine_root_children", "az_engine_play", "az_augment_count", "az_augment",
     "az_engine_set_sides", "az_engine_best_moves", "az_engine_baseline_moves", "az_engine_root_status",
@@ -71,6 +71,7 @@ def lib():
     L.az_net_time_stage.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_float)]
     L.az_net_profile.argtypes = [vp, C.c_int]
     L.az_net_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.az_net_profile_overhead.argtypes = [vp, C.POINTER(C.c_double)]
     L.az_engine_create.argtypes = [C.POINTER(EngineCfg), vp, vp, C.POINTER(vp)]
     L.az_engine_destroy.argtypes = [vp]
     L.az_engine_destroy.restype = None

@@ -948,6 +948,131 @@ __global__ __launch_bounds__(256) void k_heads(const float *__restrict__ X, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_heads2: the policy + value heads for batches from a few hundred rows up (replaces k_heads, which re-staged the whole
+// head matrix through LDS for every 32 rows: 0.32 of the MFMA peak at 32768 rows, 18 us at 4096).
+//   * workgroup = NT wavefronts, wave t owns column tile t (16 logits) of the block's RB = 16 RH rows: NT x M/RB waves fill
+//     the chip already at 4096 rows (RH = 1: 1280 waves) -- a 16-row tile with all its columns in ONE wave would leave
+//     three quarters of the SIMDs idle there;
+//   * the block's rows of h2 are copied into LDS ONCE (every 16-byte load of the block in flight together, one barrier);
+//   * the head matrix never touches LDS: it is stored in MFMA B-fragment order [K/16][NT][64 lanes][4 k-steps], a wave
+//     streams its tile's fragments from L2 with one coalesced 16-byte load per 16 k, several loads ahead of their use;
+//   * softmax as everywhere: exact maximum, az_det_expf, the row sum in ascending action order, p = e / S; tanh value.
+// Accumulation: bias, then k ascending on v_mfma_f32_16x16x4_f32 -- the same chain as k_heads / k_heads_small / the oracle.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int RH, int K>
+constexpr int heads2_lds_bytes() { return 4 * (16 * RH * (K + 2) + 16 * RH * (NT * 16 + 1) + 16 * RH); }
+
+template <int NT, int RH, int K>
+__global__ __launch_bounds__(64 * NT) void k_heads2(const float *__restrict__ X, const float *__restrict__ Wq, const float *__restrict__ bh,
+                                                    int M, int A, float *__restrict__ probs, float *__restrict__ value,
+                                                    const int *__restrict__ dyn_count) {
+    if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
+    constexpr int NH = NT * 16, RB = 16 * RH, XSTR = K + 2, NTHR = 64 * NT, NKB = K / 16, PF = 4;  // PF: fragment loads in flight
+    static_assert(K % 16 == 0 && NKB >= PF && 8 * RB <= NTHR + 64, "tile plan");
+    const int brow0 = blockIdx.x * RB;
+    if (brow0 >= M) return;  // uniform
+    extern __shared__ __attribute__((aligned(16))) float h2s[];
+    float *Xs = h2s;                      // [RB][XSTR]
+    float *Ls = Xs + RB * XSTR;           // [RB][NH + 1]
+    float *rsum = Ls + RB * (NH + 1);     // [RB]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kq = lane >> 4;
+    // this wave's fragments: Wq[kb][wave][lane] (float4 = k-steps 4 kb .. 4 kb + 3); the first PF are requested before
+    // the rows are staged, so their L2 latency overlaps the staging
+    const float4 *wq = reinterpret_cast<const float4 *>(Wq) + (size_t)wave * 64 + lane;
+    float4 bq[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) bq[p] = wq[(size_t)p * NT * 64];
+    const float bv = bh[wave * 16 + m];
+    {   // the block's rows of X -> LDS (rows past M repeat the last row: finite operands, never stored)
+        constexpr int NV = RB * K / 4, C = (NV + NTHR - 1) / NTHR;
+        float4 rx[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int q = tid + NTHR * i;
+            rx[i] = make_float4(0, 0, 0, 0);
+            if (NV % NTHR == 0 || q < NV) {
+                int row = brow0 + q / (K / 4);
+                row = row < M ? row : M - 1;
+                rx[i] = reinterpret_cast<const float4 *>(X + (size_t)row * K)[q % (K / 4)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int q = tid + NTHR * i;
+            if (NV % NTHR == 0 || q < NV) {
+                float *d = Xs + (q / (K / 4)) * XSTR + 4 * (q % (K / 4));  // 8-byte aligned (XSTR is even)
+                *reinterpret_cast<float2 *>(d) = make_float2(rx[i].x, rx[i].y);
+                *reinterpret_cast<float2 *>(d + 2) = make_float2(rx[i].z, rx[i].w);
+            }
+        }
+    }
+    __syncthreads();
+    f32x4 acc[RH];
+#pragma unroll
+    for (int h = 0; h < RH; ++h) acc[h] = (f32x4){bv, bv, bv, bv};
+    const float *xa = Xs + m * XSTR + kq;  // A fragment of k-step ks, row half h: xa[h * 16 * XSTR + 4 * ks]
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const float4 b = bq[kb % PF];
+        if (kb + PF < NKB) bq[kb % PF] = wq[(size_t)(kb + PF) * NT * 64];
+        float a[4][RH];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < RH; ++h) a[i][h] = xa[h * 16 * XSTR + 16 * kb + 4 * i];
+        __builtin_amdgcn_sched_barrier(0);  // loads stay issued ahead of this block's MFMAs
+#pragma unroll
+        for (int h = 0; h < RH; ++h) {
+            acc[h] = MFMA(a[0][h], b.x, acc[h]);
+            acc[h] = MFMA(a[1][h], b.y, acc[h]);
+            acc[h] = MFMA(a[2][h], b.z, acc[h]);
+            acc[h] = MFMA(a[3][h], b.w, acc[h]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // C layout of 16x16x4: column lane & 15, rows 4 (lane >> 4) + r
+#pragma unroll
+    for (int h = 0; h < RH; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ls[(16 * h + 4 * kq + r) * (NH + 1) + wave * 16 + m] = acc[h][r];
+    __syncthreads();
+    // softmax (base.py:355 exp(log_softmax)), 8 lanes per row: max and exp in parallel, the row sum by one lane in
+    // ascending action order
+    const int row_l = tid >> 3, sub = tid & 7;
+    float vlogit = 0.0f;
+    if (row_l < RB) {
+        float *lrow = Ls + row_l * (NH + 1);
+        float mx = -__builtin_inff();
+        for (int a = sub; a < A; a += 8) mx = fmaxf(mx, lrow[a]);
+#pragma unroll
+        for (int o = 4; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 8));
+        vlogit = lrow[A];
+        for (int a = sub; a < A; a += 8) lrow[a] = az_det_expf(lrow[a] - mx);
+    }
+    __syncthreads();
+    if (tid < RB) {
+        const float *l = Ls + tid * (NH + 1);
+        float s = 0.0f;
+        int a = 0;
+        for (; a + 8 <= A; a += 8) {
+            float t0 = l[a], t1 = l[a + 1], t2 = l[a + 2], t3 = l[a + 3], t4 = l[a + 4], t5 = l[a + 5], t6 = l[a + 6], t7 = l[a + 7];
+            s += t0; s += t1; s += t2; s += t3; s += t4; s += t5; s += t6; s += t7;
+        }
+        for (; a < A; ++a) s += l[a];
+        rsum[tid] = s;
+    }
+    __syncthreads();
+    if (row_l < RB && sub == 0 && brow0 + row_l < M) value[brow0 + row_l] = az_det_tanhf(vlogit);
+    // the block's RB x A probabilities are one contiguous run of the output: coalesced stores
+    const int n_rows = (M - brow0) < RB ? (M - brow0) : RB;
+    for (int idx = tid; idx < n_rows * A; idx += NTHR) {
+        const int r = idx / A, a = idx - r * A;
+        probs[(size_t)brow0 * A + idx] = Ls[r * (NH + 1) + a] / rsum[r];
+    }
+}
+
 // Heads for a handful of rows: one workgroup per row, one lane per logit (fmaf in k order, as k_dense_small), then the
 // same softmax / tanh arithmetic as k_heads (exact max, az_det_expf, sum in ascending action order).  ~7 us against 15.
 __global__ __launch_bounds__(128) void k_heads_small(const float *__restrict__ X, const float *__restrict__ Wh, const float *__restrict__ bh,
@@ -1004,54 +1129,104 @@ __global__ __launch_bounds__(128) void k_heads_small(const float *__restrict__ X
 // ---------------------------------------------------------------------------------------------
 // k_tail_small: fc1 + fc2 + heads of the SMALL conv nets (Connect4Net: 192 -> 64 -> 32 -> 7 + 1, connect4.py:382-412) in
 // one launch.  At these widths the three dense stages are 29 KFLOP per board against 1.28 MFLOP of convolutions: as three
-// kernels they cost three dependent launches of 4-6 us each (latency, not work).  Here one wavefront takes R rows through
-// all three layers without leaving its registers:
-//   fc1   lane n owns output n (F1 = 64): acc[r] = fmaf(x[r][k], W1[k][n], acc[r]) for k ascending -- x through scalar
-//         loads (wave-uniform address), W1[k][.] one coalesced 256-byte load per k shared by the R rows
-//   fc2   the k-th operand h1[r][k] sits in lane k's register: v_readlane broadcasts it (k is a compile-time constant)
-//   heads the same, lanes 0 .. NH-1; softmax over the A policy logits with the exact maximum, az_det_expf and the sum in
-//         ascending action order (as k_heads / the oracle), tanh of logit A
+// kernels they cost three dependent launches of 4-6 us each (latency, not work).  One workgroup takes 4 x R rows through
+// all three layers:
+//   * ONE memory round trip: the three weight matrices (58 KB), the biases and the rows' features are copied into LDS
+//     with every 16-byte load of the block in flight at once;
+//   * fc1   lane n of a wave owns output n (F1 = 64) for the wave's R rows: acc[r] = fmaf(x[r][k], W1[k][n], acc[r]) for k
+//           ascending -- x[r][k..k+3] one LDS broadcast read, W1[k][.] one conflict-free 256-byte LDS read shared by the rows;
+//   * fc2   the k-th operand h1[r][k] sits in lane k's register: v_readlane broadcasts it (k is a compile-time constant);
+//   * heads the same, lanes 0 .. NH-1; softmax over the A policy logits with the exact maximum, az_det_expf and the sum in
+//           ascending action order (as k_heads / the oracle), tanh of logit A.
 // Every output is the k-ascending fmaf chain the MFMA tiles compute: bit-identical to the three-kernel path.
 // ---------------------------------------------------------------------------------------------
 AZ_D float readlane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+template <int FIN, int F1, int F2, int NH, int R>
+constexpr int tail_lds_floats() { return FIN * F1 + F1 * F2 + F2 * NH + F1 + F2 + NH + 4 * R * FIN; }
 
 template <int FIN, int F1, int F2, int NH, int A, int R>
 __global__ __launch_bounds__(256) void k_tail_small(const float *__restrict__ feat, const float *__restrict__ W1, const float *__restrict__ b1,
                                                     const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ Wh,
                                                     const float *__restrict__ bh, int M, float *__restrict__ probs, float *__restrict__ value,
                                                     const int *__restrict__ dyn_count) {
-    static_assert(F1 == 64 && F2 <= 64 && NH <= 64 && A < NH && FIN % 16 == 0, "one lane per fc1 output");
+    static_assert(F1 == 64 && F2 <= 64 && NH <= 64 && A < NH && FIN % 4 == 0 && (FIN * F1) % 4 == 0 && (F1 * F2) % 4 == 0 && (F2 * NH) % 4 == 0,
+                  "one lane per fc1 output; 16-byte copies");
     if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
-    const int lane = threadIdx.x & 63;
-    const int row0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)) * R);
-    if (row0 >= M) return;  // waves are independent: no workgroup barrier
-    int rows[R];
+    constexpr int ROWS = 4 * R;
+    const int brow0 = blockIdx.x * ROWS;
+    if (brow0 >= M) return;  // uniform for the workgroup
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    float *w1s = tsm, *w2s = w1s + FIN * F1, *whs = w2s + F1 * F2, *b1s = whs + F2 * NH, *b2s = b1s + F1, *bhs = b2s + F2, *xs = bhs + NH;
+    const int tid = threadIdx.x;
+    {   // every load first, then every LDS store: one round trip for the whole block
+        constexpr int NW1 = FIN * F1 / 4, NW2 = F1 * F2 / 4, NWH = F2 * NH / 4, NX = ROWS * FIN / 4;
+        constexpr int C1 = (NW1 + 255) / 256, C2 = (NW2 + 255) / 256, CH_ = (NWH + 255) / 256, CX = (NX + 255) / 256;
+        float4 r1[C1], r2[C2], rh[CH_], rx[CX];
+#define IN_(N, q) (((N) % 256 == 0) || (q) < (N))  /* compile-time true where the copy is a whole number of rounds */
 #pragma unroll
-    for (int r = 0; r < R; ++r) rows[r] = row0 + r < M ? row0 + r : M - 1;  // wave-uniform, in bounds
-    float acc[R];
-    {
-        const float bv = b1[lane];
+        for (int i = 0; i < C1; ++i) r1[i] = make_float4(0, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = bv;
+        for (int i = 0; i < C2; ++i) r2[i] = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < CH_; ++i) rh[i] = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < CX; ++i) rx[i] = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C1; ++i) { const int q = tid + 256 * i; if (IN_(NW1, q)) r1[i] = reinterpret_cast<const float4 *>(W1)[q]; }
+#pragma unroll
+        for (int i = 0; i < C2; ++i) { const int q = tid + 256 * i; if (IN_(NW2, q)) r2[i] = reinterpret_cast<const float4 *>(W2)[q]; }
+#pragma unroll
+        for (int i = 0; i < CH_; ++i) { const int q = tid + 256 * i; if (IN_(NWH, q)) rh[i] = reinterpret_cast<const float4 *>(Wh)[q]; }
+#pragma unroll
+        for (int i = 0; i < CX; ++i) {
+            const int q = tid + 256 * i;
+            if (IN_(NX, q)) {
+                int row = brow0 + q / (FIN / 4);
+                row = row < M ? row : M - 1;
+                rx[i] = reinterpret_cast<const float4 *>(feat + (size_t)row * FIN)[q % (FIN / 4)];
+            }
+        }
+        float bb = 0.0f;
+        if (tid < F1) bb = b1[tid]; else if (tid < F1 + F2) bb = b2[tid - F1]; else if (tid < F1 + F2 + NH) bb = bh[tid - F1 - F2];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) { const int q = tid + 256 * i; if (IN_(NW1, q)) reinterpret_cast<float4 *>(w1s)[q] = r1[i]; }
+#pragma unroll
+        for (int i = 0; i < C2; ++i) { const int q = tid + 256 * i; if (IN_(NW2, q)) reinterpret_cast<float4 *>(w2s)[q] = r2[i]; }
+#pragma unroll
+        for (int i = 0; i < CH_; ++i) { const int q = tid + 256 * i; if (IN_(NWH, q)) reinterpret_cast<float4 *>(whs)[q] = rh[i]; }
+#pragma unroll
+        for (int i = 0; i < CX; ++i) { const int q = tid + 256 * i; if (IN_(NX, q)) reinterpret_cast<float4 *>(xs)[q] = rx[i]; }
+        if (tid < F1 + F2 + NH) b1s[tid] = bb;  // b1s, b2s, bhs are contiguous
+#undef IN_
     }
-    for (int k0 = 0; k0 < FIN; k0 += 16) {
-        float w[16];
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int row0 = brow0 + wave * R;
+    const float *xw = xs + wave * R * FIN;
+    float acc[R];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) w[i] = W1[(size_t)(k0 + i) * F1 + lane];
+    for (int r = 0; r < R; ++r) acc[r] = b1s[lane];
+#pragma unroll 4
+    for (int k = 0; k < FIN; k += 4) {
+        float w[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < 4; ++i) w[i] = w1s[(k + i) * F1 + lane];
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fmaf(feat[(size_t)rows[r] * FIN + k0 + i], w[i], acc[r]);
+        for (int r = 0; r < R; ++r) {
+            const float4 x = *reinterpret_cast<const float4 *>(xw + r * FIN + k);  // same address in every lane: broadcast
+            acc[r] = fmaf(x.x, w[0], acc[r]); acc[r] = fmaf(x.y, w[1], acc[r]);
+            acc[r] = fmaf(x.z, w[2], acc[r]); acc[r] = fmaf(x.w, w[3], acc[r]);
+        }
     }
     float h1[R], a2[R];
     {
         const int n2 = lane < F2 ? lane : F2 - 1;
-        const float bv = b2[n2];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { h1[r] = acc[r] > 0.0f ? acc[r] : 0.0f; a2[r] = bv; }
+        for (int r = 0; r < R; ++r) { h1[r] = acc[r] > 0.0f ? acc[r] : 0.0f; a2[r] = b2s[n2]; }
 #pragma unroll
         for (int k = 0; k < F1; ++k) {
-            const float w = W2[k * F2 + n2];
+            const float w = w2s[k * F2 + n2];
 #pragma unroll
             for (int r = 0; r < R; ++r) a2[r] = fmaf(readlane_f(h1[r], k), w, a2[r]);
         }
@@ -1059,12 +1234,11 @@ __global__ __launch_bounds__(256) void k_tail_small(const float *__restrict__ fe
     float h2[R], lg[R];
     {
         const int j = lane < NH ? lane : NH - 1;
-        const float bv = bh[j];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { h2[r] = a2[r] > 0.0f ? a2[r] : 0.0f; lg[r] = bv; }
+        for (int r = 0; r < R; ++r) { h2[r] = a2[r] > 0.0f ? a2[r] : 0.0f; lg[r] = bhs[j]; }
 #pragma unroll
         for (int k = 0; k < F2; ++k) {
-            const float w = Wh[k * NH + j];
+            const float w = whs[k * NH + j];
 #pragma unroll
             for (int r = 0; r < R; ++r) lg[r] = fmaf(readlane_f(h2[r], k), w, lg[r]);
         }
@@ -1121,6 +1295,7 @@ struct az_net {
     std::vector<void *> allocs;
     TrunkParams tp;
     float *fc1w, *fc1b, *fc2w, *fc2b, *hw, *hb;
+    float *hwq = nullptr;  // head matrix in 16x16x4 B-fragment order [F2/16][NH/16][64 lanes][4] (k_heads2)
     float *feat, *h1, *h2;
     MlpParams mlp;           // host staging of the TicTacToe MLP
     MlpParams *mlp_dev = nullptr;  // what k_mlp reads
@@ -1131,6 +1306,7 @@ struct az_net {
     std::vector<hipEvent_t> prof_ev;  // [PROF_SLOTS][5]
     std::vector<int> prof_kind;       // trunk kernel used by the forward in that slot
     int prof_used = 0;
+    double prof_empty_ms = -1.0;  // what an event-to-event interval costs with NO kernel in it (calibrated on first use)
     double prof_ms[5] = {0, 0, 0, 0, 0};  // k_trunk2, fc1, fc2, heads, k_trunk (one board per wave)
     long long prof_n[5] = {0, 0, 0, 0, 0};
 };
@@ -1168,7 +1344,7 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
         NA(n->tp.w1p, 5 * 64)
         for (int l = 0; l < 3; ++l) { NA(n->tp.wp[l], 9 * 16 * 64) NA(n->tp.wq[l], 9 * 16 * 64) }
         NA(n->fc1w, (size_t)n->FIN * n->F1) NA(n->fc1b, n->F1) NA(n->fc2w, (size_t)n->F1 * n->F2) NA(n->fc2b, n->F2)
-        NA(n->hw, (size_t)n->F2 * n->NH) NA(n->hb, n->NH)
+        NA(n->hw, (size_t)n->F2 * n->NH) NA(n->hb, n->NH) NA(n->hwq, (size_t)n->F2 * n->NH)
         NA(n->feat, (size_t)max_batch * n->FIN) NA(n->h1, (size_t)max_batch * n->F1) NA(n->h2, (size_t)max_batch * n->F2)
 #undef NA
         if (rc != AZ_OK) { az_net_destroy(n); return rc; }
@@ -1344,6 +1520,16 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
         fb[n->A] = (*vb)[0];
         for (int k = 0; k < n->F2; ++k) fw[(size_t)k * n->NH + n->A] = (*vw)[k];
         AZ_TRY(upload(n->hw, fw, st)); AZ_TRY(upload(n->hb, fb, st));
+        // the same matrix in B-fragment order: [kb][nt][lane][i] = Wh[k = 16 kb + 4 i + (lane >> 4)][n = 16 nt + (lane & 15)]
+        const int NT = n->NH / 16;
+        std::vector<float> fq((size_t)n->F2 * n->NH, 0.0f);
+        if (n->F2 % 16 == 0)
+            for (int kb = 0; kb < n->F2 / 16; ++kb)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 4; ++i)
+                            fq[(((size_t)kb * NT + nt) * 64 + lane) * 4 + i] = fw[(size_t)(16 * kb + 4 * i + (lane >> 4)) * n->NH + 16 * nt + (lane & 15)];
+        AZ_TRY(upload(n->hwq, fq, st));
     }
     n->committed = true;
     return AZ_OK;
@@ -1354,7 +1540,7 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
 // trainer.py:383-387): one thread per destination element, float64 arithmetic in the host code's operation order
 // (no contraction), so both paths produce identical bits.
 // ---------------------------------------------------------------------------------------------
-enum { FOLD_BIAS = 0, FOLD_W1F, FOLD_W1P, FOLD_WP, FOLD_WQ, FOLD_DENSE_T, FOLD_HEADS_W, FOLD_HEADS_B };
+enum { FOLD_BIAS = 0, FOLD_W1F, FOLD_W1P, FOLD_WP, FOLD_WQ, FOLD_DENSE_T, FOLD_HEADS_W, FOLD_HEADS_WQ, FOLD_HEADS_B };
 struct FoldJob {
     int mode, n_dst, K, N, A;
     const float *w, *b, *g, *beta, *mean, *var;  // w: the layer's weight (heads: fc_probs.weight), b: bias (heads: fc_value.*)
@@ -1399,6 +1585,12 @@ __global__ void k_fold(FoldJob j) {
         }
         case FOLD_HEADS_W: {  // dst[k][a] = fc_probs.weight[a][k] | fc_value.weight[k] | 0   (row width N)
             const int a = i % j.N, k = i / j.N;
+            out = a < j.A ? j.w[(size_t)a * j.K + k] : (a == j.A ? j.b[k] : 0.0f);
+            break;
+        }
+        case FOLD_HEADS_WQ: {  // the same in 16x16x4 B-fragment order [kb][nt][lane][i]: k = 16 kb + 4 i + (lane >> 4), a = 16 nt + (lane & 15)
+            const int ii = i % 4, lane = (i / 4) % 64, NT = j.N / 16, nt = (i / 256) % NT, kb = i / (256 * NT);
+            const int k = 16 * kb + 4 * ii + (lane >> 4), a = 16 * nt + (lane & 15);
             out = a < j.A ? j.w[(size_t)a * j.K + k] : (a == j.A ? j.b[k] : 0.0f);
             break;
         }
@@ -1483,6 +1675,8 @@ extern "C" int az_net_commit_device(az_net *n, void *stream) {
     AZ_TRY(fold_launch(n, FOLD_BIAS, n->fc2b, n->F2, "", 0, "fc2.bias", n->F2, "fc_bn2", n->F2, 0, 0, 0, st));
     AZ_TRY(fold_launch(n, FOLD_HEADS_W, n->hw, n->F2 * n->NH, "fc_probs.weight", (size_t)n->A * n->F2, "fc_value.weight", n->F2, "", 0, n->F2, n->NH, n->A, st));
     AZ_TRY(fold_launch(n, FOLD_HEADS_B, n->hb, n->NH, "fc_probs.bias", n->A, "fc_value.bias", 1, "", 0, 0, n->NH, n->A, st));
+    if (n->F2 % 16 == 0)
+        AZ_TRY(fold_launch(n, FOLD_HEADS_WQ, n->hwq, n->F2 * n->NH, "fc_probs.weight", (size_t)n->A * n->F2, "fc_value.weight", n->F2, "", 0, n->F2, n->NH, n->A, st));
     AZ_HIP(hipGetLastError());
     n->committed = true;
     return AZ_OK;
@@ -1601,10 +1795,30 @@ static int heads_go(az_net *n, int B, float *probs, float *value, const int *dyn
     return AZ_OK;
 }
 
+template <int NT, int RH>
+static int heads2_go(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
+    constexpr int lds = heads2_lds_bytes<NT, RH, 512>();
+    static_assert(lds <= 160 * 1024, "k_heads2 does not fit the CU's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_heads2<NT, RH, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_heads2<NT, RH, 512>), dim3((unsigned)((B + 16 * RH - 1) / (16 * RH))), dim3(64 * NT), lds, st, n->h2, n->hwq, n->hb, B, n->A,
+                       probs, value, dyn);
+    return AZ_OK;
+}
+
 static int launch_heads(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
     if (B <= 128 && n->NH <= 128 && n->F2 % 32 == 0) {  // few rows: latency, not throughput
         hipLaunchKernelGGL(k_heads_small, dim3((unsigned)B), dim3(128), 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, n->NH, probs, value, dyn);
         return AZ_OK;
+    }
+    static int v1 = -1;
+    if (v1 < 0) { const char *e = getenv("AZ_HEADS_V1"); v1 = (e && atoi(e)) ? 1 : 0; }  // the round-1 kernel, for A/B runs
+    if (!v1 && n->F2 == 512) {  // OthelloNet: a 16-row tile per block below 8192 rows (more waves), 32 rows above (half the weight re-reads)
+        if (n->NH == 80) return B >= 8192 ? heads2_go<5, 2>(n, B, probs, value, dyn, st) : heads2_go<5, 1>(n, B, probs, value, dyn, st);
+        if (n->NH == 48) return B >= 8192 ? heads2_go<3, 2>(n, B, probs, value, dyn, st) : heads2_go<3, 1>(n, B, probs, value, dyn, st);
     }
     switch (n->NH / 16) {
         case 1: return heads_go<1>(n, B, probs, value, dyn, st);
@@ -1618,15 +1832,25 @@ static int launch_heads(az_net *n, int B, float *probs, float *value, const int 
 static bool tail_is_fused(const az_net *n) {
     static int off = -1;
     if (off < 0) { const char *e = getenv("AZ_NO_FUSED_TAIL"); off = (e && atoi(e)) ? 1 : 0; }
-    return !off && n->F1 == 64 && n->F2 == 32 && n->NH == 16 && ((n->FIN == 192 && n->A == 7) || (n->FIN == 512 && n->A == 8));
+    return !off && n->F1 == 64 && n->F2 == 32 && n->NH == 16 && n->FIN == 192 && n->A == 7;  // Connect4 6x7 (8x8: 131 KB of fc1 weights, not worth restaging)
+}
+
+template <int FIN, int A>
+static int tail_go(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
+    constexpr int R = 4, lds = 4 * tail_lds_floats<FIN, 64, 32, 16, R>();
+    static_assert(lds <= 160 * 1024, "k_tail_small does not fit the CU's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_small<FIN, 64, 32, 16, A, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_tail_small<FIN, 64, 32, 16, A, R>), dim3((unsigned)((B + 4 * R - 1) / (4 * R))), dim3(256), lds, st, n->feat, n->fc1w,
+                       n->fc1b, n->fc2w, n->fc2b, n->hw, n->hb, B, probs, value, dyn);
+    return AZ_OK;
 }
 
 static int launch_tail(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
-    constexpr int R = 4;
-    const dim3 grid((unsigned)((B + 4 * R - 1) / (4 * R))), block(256);
-    if (n->FIN == 192) hipLaunchKernelGGL((k_tail_small<192, 64, 32, 16, 7, R>), grid, block, 0, st, n->feat, n->fc1w, n->fc1b, n->fc2w, n->fc2b, n->hw, n->hb, B, probs, value, dyn);
-    else hipLaunchKernelGGL((k_tail_small<512, 64, 32, 16, 8, R>), grid, block, 0, st, n->feat, n->fc1w, n->fc1b, n->fc2w, n->fc2b, n->hw, n->hb, B, probs, value, dyn);
-    return AZ_OK;
+    return tail_go<192, 7>(n, B, probs, value, dyn, st);
 }
 
 static int run_stage(az_net *n, int stage, const float *d_input, int B, const int *dyn, float *d_probs, float *d_value, hipStream_t st) {
@@ -1674,6 +1898,31 @@ extern "C" int az_net_profile(az_net *n, int enable) {
 
 extern "C" int az_net_profiling(const az_net *n) { return n && n->prof ? 1 : 0; }
 
+// An interval between two recorded events is not only the kernel between them: the marker packets and the dispatch
+// cost ~5 us per interval on this stack, which matters for kernels of 10-60 us.  Calibration: 64 events recorded back to
+// back on the stream, the mean gap is the cost of an EMPTY interval; az_net_profile_overhead reports it so that callers
+// can subtract it per launch (the corrected figure is the one that agrees with rocprofv3's kernel durations).
+static int prof_calibrate(az_net *n, hipStream_t st) {
+    constexpr int N = 64;
+    hipEvent_t ev[N + 1];
+    for (int i = 0; i <= N; ++i) AZ_HIP(hipEventCreate(&ev[i]));
+    for (int rep = 0; rep < 2; ++rep) {  // the first burst warms the path
+        for (int i = 0; i <= N; ++i) AZ_HIP(hipEventRecord(ev[i], st));
+        AZ_HIP(hipEventSynchronize(ev[N]));
+    }
+    double tot = 0.0;
+    for (int i = 0; i < N; ++i) { float ms = 0.0f; AZ_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); tot += ms; }
+    for (int i = 0; i <= N; ++i) (void)hipEventDestroy(ev[i]);
+    n->prof_empty_ms = tot / N;
+    return AZ_OK;
+}
+
+extern "C" int az_net_profile_overhead(az_net *n, double *ms_per_interval) {
+    AZ_REQUIRE(n && ms_per_interval, AZ_EINVAL, "null argument");
+    *ms_per_interval = n->prof_empty_ms < 0 ? 0.0 : n->prof_empty_ms;
+    return AZ_OK;
+}
+
 extern "C" int az_net_profile_read(az_net *n, double *ms_total, int64_t *launches) {
     AZ_REQUIRE(n && ms_total && launches, AZ_EINVAL, "null argument");
     AZ_TRY(prof_harvest(n));
@@ -1694,6 +1943,7 @@ static int forward_impl(az_net *n, const float *d_input, int B, const int *dyn, 
         for (int s = 0; s < 4; ++s) AZ_TRY(run_stage(n, s, d_input, B, dyn, d_probs, d_value, st));
         return AZ_OK;
     }
+    if (n->prof_empty_ms < 0) AZ_TRY(prof_calibrate(n, st));
     if (n->prof_used == PROF_SLOTS) AZ_TRY(prof_harvest(n));
     hipEvent_t *ev = n->prof_ev.data() + (size_t)n->prof_used * 5;
     AZ_HIP(hipEventRecord(ev[0], st));

@@ -158,6 +158,12 @@ class HipNet:
         names = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads", "k_trunk"]
         return {k: (ms[i], n[i]) for i, k in enumerate(names)}
 
+    def profile_overhead_ms(self):
+        """what one event-to-event interval costs without a kernel in it (subtract per launch from profile_read totals)"""
+        ms = C.c_double()
+        check(lib().az_net_profile_overhead(self.h, C.byref(ms)))
+        return float(ms.value)
+
     def close(self):
         if getattr(self, "h", None):
             lib().az_net_destroy(self.h)

@@ -104,6 +104,9 @@ int az_net_time_stage(az_net *net, int stage, int B, int iters, void *stream, fl
 int az_net_profile(az_net *net, int enable);
 int az_net_profiling(const az_net *net); /* 1 while enabled (the engine then launches kernel by kernel instead of replaying graphs) */
 int az_net_profile_read(az_net *net, double *ms_total, int64_t *launches);
+/* cost of one event-to-event interval with no kernel in it (calibrated when profiling first runs): subtract it per launch
+ * from ms_total to compare with rocprofv3's kernel durations */
+int az_net_profile_overhead(az_net *net, double *ms_per_interval);
 
 /* ---- self-play engine (K3/K4/K7/K8/K9) -------------------------------------------------------
  * replaces AlphaZeroTrainer.self_play (trainer.py:215-273) driving AlphaZeroPlayer.get_move
