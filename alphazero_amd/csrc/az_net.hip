@@ -969,7 +969,7 @@ __global__ __launch_bounds__(64 * NT) void k_heads2(const float *__restrict__ X,
                                                     const int *__restrict__ dyn_count) {
     if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
     constexpr int NH = NT * 16, RB = 16 * RH, XSTR = K + 2, NTHR = 64 * NT, NKB = K / 16, PF = 4;  // PF: fragment loads in flight
-    static_assert(K % 16 == 0 && NKB >= PF && 8 * RB <= NTHR + 64, "tile plan");
+    static_assert(K % 16 == 0 && NKB >= PF && RB <= NTHR && NTHR % 8 == 0, "tile plan");
     const int brow0 = blockIdx.x * RB;
     if (brow0 >= M) return;  // uniform
     extern __shared__ __attribute__((aligned(16))) float h2s[];
@@ -1040,15 +1040,14 @@ __global__ __launch_bounds__(64 * NT) void k_heads2(const float *__restrict__ X,
     __syncthreads();
     // softmax (base.py:355 exp(log_softmax)), 8 lanes per row: max and exp in parallel, the row sum by one lane in
     // ascending action order
-    const int row_l = tid >> 3, sub = tid & 7;
-    float vlogit = 0.0f;
-    if (row_l < RB) {
+    const int sub = tid & 7;
+    for (int row_l = tid >> 3; row_l < RB; row_l += NTHR / 8) {
         float *lrow = Ls + row_l * (NH + 1);
         float mx = -__builtin_inff();
         for (int a = sub; a < A; a += 8) mx = fmaxf(mx, lrow[a]);
 #pragma unroll
         for (int o = 4; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 8));
-        vlogit = lrow[A];
+        if (sub == 0 && brow0 + row_l < M) value[brow0 + row_l] = az_det_tanhf(lrow[A]);
         for (int a = sub; a < A; a += 8) lrow[a] = az_det_expf(lrow[a] - mx);
     }
     __syncthreads();
@@ -1064,7 +1063,6 @@ __global__ __launch_bounds__(64 * NT) void k_heads2(const float *__restrict__ X,
         rsum[tid] = s;
     }
     __syncthreads();
-    if (row_l < RB && sub == 0 && brow0 + row_l < M) value[brow0 + row_l] = az_det_tanhf(vlogit);
     // the block's RB x A probabilities are one contiguous run of the output: coalesced stores
     const int n_rows = (M - brow0) < RB ? (M - brow0) : RB;
     for (int idx = tid; idx < n_rows * A; idx += NTHR) {
@@ -1816,9 +1814,13 @@ static int launch_heads(az_net *n, int B, float *probs, float *value, const int 
     }
     static int v1 = -1;
     if (v1 < 0) { const char *e = getenv("AZ_HEADS_V1"); v1 = (e && atoi(e)) ? 1 : 0; }  // the round-1 kernel, for A/B runs
-    if (!v1 && n->F2 == 512) {  // OthelloNet: a 16-row tile per block below 8192 rows (more waves), 32 rows above (half the weight re-reads)
-        if (n->NH == 80) return B >= 8192 ? heads2_go<5, 2>(n, B, probs, value, dyn, st) : heads2_go<5, 1>(n, B, probs, value, dyn, st);
-        if (n->NH == 48) return B >= 8192 ? heads2_go<3, 2>(n, B, probs, value, dyn, st) : heads2_go<3, 1>(n, B, probs, value, dyn, st);
+    static int rh = -1;
+    if (rh < 0) { const char *e = getenv("AZ_HEADS_RH"); rh = e ? atoi(e) : 0; }  // tuning: force 16-row (1) / 32-row (2) blocks
+    if (!v1 && n->F2 == 512) {  // OthelloNet.  Measured (us, 16-row / 32-row blocks; round-1 kernel): 4096 rows 9.9 / 14.5 / 15.5,
+        // 8192: 13.6 / 15.0, 16384: 20.3 / 21.4, 32768: 39.0 / 55.7 / 44.4 -> 16-row blocks (more waves in flight) everywhere
+        const bool two = rh == 2;
+        if (n->NH == 80) return two ? heads2_go<5, 2>(n, B, probs, value, dyn, st) : heads2_go<5, 1>(n, B, probs, value, dyn, st);
+        if (n->NH == 48) return two ? heads2_go<3, 2>(n, B, probs, value, dyn, st) : heads2_go<3, 1>(n, B, probs, value, dyn, st);
     }
     switch (n->NH / 16) {
         case 1: return heads_go<1>(n, B, probs, value, dyn, st);
@@ -1835,9 +1837,9 @@ static bool tail_is_fused(const az_net *n) {
     return !off && n->F1 == 64 && n->F2 == 32 && n->NH == 16 && n->FIN == 192 && n->A == 7;  // Connect4 6x7 (8x8: 131 KB of fc1 weights, not worth restaging)
 }
 
-template <int FIN, int A>
+template <int FIN, int A, int R>
 static int tail_go(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
-    constexpr int R = 4, lds = 4 * tail_lds_floats<FIN, 64, 32, 16, R>();
+    constexpr int lds = 4 * tail_lds_floats<FIN, 64, 32, 16, R>();
     static_assert(lds <= 160 * 1024, "k_tail_small does not fit the CU's LDS");
     static bool attr_set = false;
     if (!attr_set) {
@@ -1850,7 +1852,10 @@ static int tail_go(az_net *n, int B, float *probs, float *value, const int *dyn,
 }
 
 static int launch_tail(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
-    return tail_go<192, 7>(n, B, probs, value, dyn, st);
+    static int r8 = -1;
+    if (r8 < 0) { const char *e = getenv("AZ_TAIL_R8_FROM"); r8 = e ? atoi(e) : 0x7fffffff; }
+    // 16 rows per workgroup (measured: 9.3 us up to 4096 rows, 12.7 us at 8192; 32 rows per workgroup: 19 us at every size)
+    return B >= r8 ? tail_go<192, 7, 8>(n, B, probs, value, dyn, st) : tail_go<192, 7, 4>(n, B, probs, value, dyn, st);
 }
 
 static int run_stage(az_net *n, int stage, const float *d_input, int B, const int *dyn, float *d_probs, float *d_value, hipStream_t st) {
