@@ -107,6 +107,38 @@ def test_trainer_self_play_equals_oracle_and_trains(tmp_path):
     assert len(m) != len(first_actions) or not np.array_equal(m[:, 3], first_actions)
 
 
+@pytest.mark.parametrize("game", ["othello", "tictactoe"])
+def test_second_iteration_plays_with_the_trained_weights(game, tmp_path):
+    """the trainer keeps ONE engine (its searches replay captured HIP graphs) and re-uploads the weights every
+    iteration -- the second self-play must be the oracle's self-play with the TRAINED weights, sample for sample, on the
+    host fold (config.device = "cpu") and on the device fold ("cuda")."""
+    from alphazero_amd.games.tictactoe import TicTacToeConfig
+    base.DEFAULT_MODELS_PATH = str(tmp_path) + "/"
+    for device in ("cpu", "cuda"):
+        tr = AlphaZeroTrainer(verbose=False, engine_slots=16, seed=5, materialize_memory=False)
+        tr.game = game
+        if game == "othello":
+            tr.config = OthelloConfig(board_size=6, simulations=10, episodes=16, epochs=1, batch_size=32, iterations=2, do_eval=False, device=device)
+        else:
+            tr.config = TicTacToeConfig(simulations=10, episodes=16, epochs=1, batch_size=16, iterations=2, do_eval=False, device=device)
+        torch.manual_seed(1)
+        tr.setup()
+        sd0 = {k: v.detach().cpu().numpy().copy() for k, v in tr.nn.state_dict().items() if not k.endswith("num_batches_tracked")}
+        tr.self_play(0); tr.optimize_network(0); tr.update_network(0)
+        tr.self_play(1)
+        sd = {k: v.detach().cpu().numpy() for k, v in tr.nn.state_dict().items() if not k.endswith("num_batches_tracked")}
+        if game == "othello":
+            new, old, dims, kind = O.ConvNet(O.OTHELLO, 6, 6, sd), O.ConvNet(O.OTHELLO, 6, 6, sd0), (O.OTHELLO, 6, 6), "conv"
+        else:
+            new, old, dims, kind = O.MlpNet(sd), O.MlpNet(sd0), (O.TICTACTOE, 3, 3), "mlp"
+        ref = O.selfplay(*dims, 16, 10, (kind, new), seed=5, first_game_id=16)
+        stale = O.selfplay(*dims, 16, 10, (kind, old), seed=5, first_game_id=16)
+        got = {k: v.cpu().numpy() for k, v in tr.device_samples.items()}
+        assert not (len(ref["z"]) == len(stale["z"]) and np.array_equal(ref["visits"], stale["visits"])), "training changed nothing: test proves nothing"
+        assert np.array_equal(got["state"], ref["state"]) and np.array_equal(got["pi"], ref["pi"]) and np.array_equal(got["z"], ref["z"]), (game, device)
+        assert np.array_equal(got["meta"][:, 1], ref["meta"][:, 1]) and np.array_equal(got["meta"][:, 0] + 16, ref["meta"][:, 0])
+
+
 def test_trainer_full_loop_tictactoe(tmp_path):
     base.DEFAULT_MODELS_PATH = str(tmp_path) + "/"
     cfg = TicTacToeConfig(simulations=8, episodes=32, epochs=1, batch_size=16, iterations=2, eval_opponent="random",

@@ -24,9 +24,10 @@ def find(d, suffix):
     return hits[0] if hits else None
 
 
-stats = find(f"{tag}_prof", "kernel_stats.csv")
-if stats:
-    open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w").write(open(stats).read())
+for d, name in ((f"{tag}_prof", f"{tag}_kernel_stats.csv"), (f"{tag}_prof_c2", f"{tag}_c2_kernel_stats.csv"), (f"{tag}_prof_c4", f"{tag}_c4_kernel_stats.csv")):
+    stats = find(d, "kernel_stats.csv")
+    if stats:
+        open(os.path.join(out, name), "w").write(open(stats).read())
 
 
 def classify(name, game):

@@ -34,6 +34,12 @@ cp $OUT/${TAG}_kstep_counters.json profiles/kstep_counters.json 2>/dev/null
 python3 bench.py > $OUT/${TAG}_bench.log 2>&1
 grep '^{' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench.json
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o k -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o k -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-literal-configs > $OUT/${TAG}_prof.log 2>&1
+# the literal BASELINE configs, one process each, so that their kernels do not mix in one table
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_c2 -o k -- python3 $R/tools/run_config.py othello 4096 > $OUT/${TAG}_prof_c2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_c4 -o k -- python3 $R/tools/run_config.py connect4 8192 > $OUT/${TAG}_prof_c4.log 2>&1
 cd $R
 python3 tools/collect_profiles.py $TAG
+# gpurun copies back at most 64 MiB: keep the condensed files, drop the raw per-dispatch tables
+rm -rf $OUT/${TAG}_pmc_* $OUT/${TAG}_kstep_* $OUT/${TAG}_prof $OUT/${TAG}_prof_c2 $OUT/${TAG}_prof_c4
+ls -la $OUT | grep ${TAG}_
