@@ -131,8 +131,9 @@ def test_second_iteration_plays_with_the_trained_weights(game, tmp_path):
             new, old, dims, kind = O.ConvNet(O.OTHELLO, 6, 6, sd), O.ConvNet(O.OTHELLO, 6, 6, sd0), (O.OTHELLO, 6, 6), "conv"
         else:
             new, old, dims, kind = O.MlpNet(sd), O.MlpNet(sd0), (O.TICTACTOE, 3, 3), "mlp"
-        ref = O.selfplay(*dims, 16, 10, (kind, new), seed=5, first_game_id=16)
-        stale = O.selfplay(*dims, 16, 10, (kind, old), seed=5, first_game_id=16)
+        tk = dict(temp_max_step=tr.config.temp_max_step, temp_min_step=tr.config.temp_min_step)  # TicTacToe: 2 / 2, Othello: 4 / 4
+        ref = O.selfplay(*dims, 16, 10, (kind, new), seed=5, first_game_id=16, **tk)
+        stale = O.selfplay(*dims, 16, 10, (kind, old), seed=5, first_game_id=16, **tk)
         got = {k: v.cpu().numpy() for k, v in tr.device_samples.items()}
         assert not (len(ref["z"]) == len(stale["z"]) and np.array_equal(ref["visits"], stale["visits"])), "training changed nothing: test proves nothing"
         assert np.array_equal(got["state"], ref["state"]) and np.array_equal(got["pi"], ref["pi"]) and np.array_equal(got["z"], ref["z"]), (game, device)
