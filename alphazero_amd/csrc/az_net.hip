@@ -53,6 +53,8 @@ struct TrunkParams {
     const float *w1p;            // conv1, 32x32x2 B-fragment order [5 k-steps][64] (tap 9 zero)
     const float *wp[3];          // conv2..4, 32x32x2 B fragments, four k-steps per lane contiguous: [9 taps][4][64 lanes][4]
     const float *wq[3];          // conv2..4, 16x16x4 B fragments (k_trunk; k_trunk2's 16-row tiles): [9 taps][4][64 lanes][4] (fragment i = 2 j + nt)
+    const float *wu;             // conv2 in the Winograd F(2x2,3x3) form: U = G g' G^T as 16x16x4 B fragments
+                                 // [2 passes][8 k-steps][4][64 lanes][4]: fragment e = 2 f8 + nt of frequency f = 8 p + f8
 };
 
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -153,6 +155,127 @@ AZ_D void store_relu_lds(float *out, int lane, const f32x4 (&acc)[MT][2]) {
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// EXPERIMENTAL (AZ_WINOGRAD=1, see use_wino): conv2 ("same", 32 -> 32) of ONE board in the Winograd F(2x2,3x3) form: 2.25x
+// fewer multiplications than the direct form (conv2 is 54 % of the trunk's work).  The board's 2x2 output tiles are the rows of a 16x16x4 MFMA tile (8x8 plane:
+// 16 tiles, 7x6: 12), and for each of the 16 "frequencies" f = 4 i + j the products over the input channels are one
+// k-ordered MFMA chain:   M[f][tile][oc] = sum over ic ascending of V[f][tile][ic] * U[f][ic][oc]      (from 0)
+// with V = B^T d B of the tile's zero-padded 4x4 input patch d and U = G g' G^T folded at upload.
+//   * every lane transforms its own operand: lane (m, kq) reads the patch of tile m in plane 4 j + kq straight from the
+//     un-haloed LDS planes (out-of-plane elements are redirected to the plane's zero slot) and forms V with 16 adds;
+//   * two passes of 8 frequencies (frequency rows i = 0,1 / 2,3: patch rows 0-2 / 1-3), so that 64 accumulator registers
+//     are live instead of 128; the inverse transform Y = A^T M A is taken along the frequency COLUMNS first, which lets
+//     pass 0 hand over four values per output tile and channel (32 registers);
+//   * U arrives from L2 in B-fragment order, one k-step ahead; the next k-step's patch is read under the MFMAs.
+// Arithmetic (restated operation for operation by the CPU oracle's conv2_winograd): T = rows of B^T d, V = T B, the chains above,
+// R[i][0] = (M[i][0]+M[i][1])+M[i][2], R[i][1] = (M[i][1]-M[i][2])-M[i][3], Y[0][c] = (R[0][c]+R[1][c])+R[2][c],
+// Y[1][c] = (R[1][c]-R[2][c])-R[3][c], out = relu(Y + bias): one IEEE operation per step, in this order.
+// The output overwrites the input planes (all reads are done before the first write).
+// ---------------------------------------------------------------------------------------------
+template <int CH, int CW, int PS>
+AZ_D void conv2_wino(float *act, const float *__restrict__ wu, const float *__restrict__ bias, int lane) {
+    constexpr int TW = (CW + 1) / 2, NTL = ((CH + 1) / 2) * TW, P1 = CH * CW;
+    static_assert(NTL <= 16 && PS > P1, "one 16-row tile of 2x2 output tiles per board; a zero slot behind every plane");
+    const int m = lane & 15, kq = lane >> 4;
+    const int t = m < NTL ? m : NTL - 1;  // padding rows repeat the last tile (finite operands, never stored)
+    const int ty = t / TW, tx = t % TW;
+    const float4 *ul = reinterpret_cast<const float4 *>(wu) + lane;
+    float cu[2][4][2], cw_[2][4][2];  // pass 0 -> pass 1: R[0][c] + R[1][c] and R[1][c] per (nt, r)
+    float yo[2][4][2][2];             // Y[i][c] per (nt, r)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        int off[12];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int iy = 2 * ty - 1 + a + p, ix = 2 * tx - 1 + b;
+                off[a * 4 + b] = kq * PS + ((iy >= 0 && iy < CH && ix >= 0 && ix < CW) ? iy * CW + ix : P1);
+            }
+        f32x4 acc[8][2];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) { acc[f][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc[f][1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+        // U fragments: a ring of three k-steps, requested two k-steps (>= 1000 cycles of MFMA work) ahead of their use
+        float4 ub[3][4];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ub[jj][q] = ul[(size_t)((p * 8 + jj) * 4 + q) * 64];
+        float d[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) d[e] = act[off[e]];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float dn[12];
+            if (j + 2 < 8) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ub[(j + 2) % 3][q] = ul[(size_t)((p * 8 + j + 2) * 4 + q) * 64];
+            }
+            if (j + 1 < 8) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) dn[e] = act[off[e] + 4 * (j + 1) * PS];
+            }
+            float T[2][4], V[8];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (p == 0) { T[0][b] = d[b] - d[8 + b]; T[1][b] = d[4 + b] + d[8 + b]; }      // T[0] = d0 - d2, T[1] = d1 + d2
+                else { T[0][b] = d[4 + b] - d[b]; T[1][b] = d[b] - d[8 + b]; }                 // T[2] = d2 - d1, T[3] = d1 - d3 (rows 1..3 loaded)
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                V[4 * i + 0] = T[i][0] - T[i][2]; V[4 * i + 1] = T[i][1] + T[i][2];
+                V[4 * i + 2] = T[i][2] - T[i][1]; V[4 * i + 3] = T[i][1] - T[i][3];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the loads above stay issued ahead of this k-step's MFMAs
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                const float4 u = ub[j % 3][f >> 1];
+                acc[f][0] = MFMA(V[f], (f & 1) ? u.z : u.x, acc[f][0]);
+                acc[f][1] = MFMA(V[f], (f & 1) ? u.w : u.y, acc[f][1]);
+            }
+#pragma unroll
+            for (int f = 0; f < 8; ++f) { asm volatile("" : "+a"(acc[f][0])); asm volatile("" : "+a"(acc[f][1])); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < 8) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) d[e] = dn[e];
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float R[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    R[i][0] = (acc[4 * i + 0][nt][r] + acc[4 * i + 1][nt][r]) + acc[4 * i + 2][nt][r];
+                    R[i][1] = (acc[4 * i + 1][nt][r] - acc[4 * i + 2][nt][r]) - acc[4 * i + 3][nt][r];
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (p == 0) { cu[nt][r][c] = R[0][c] + R[1][c]; cw_[nt][r][c] = R[1][c]; }
+                    else { yo[nt][r][0][c] = cu[nt][r][c] + R[0][c]; yo[nt][r][1][c] = (cw_[nt][r][c] - R[0][c]) - R[1][c]; }
+                }
+            }
+    }
+    LDS_FENCE();  // every read of the input planes has returned: the output may overwrite them
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float bv = bias[nt * 16 + m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tt = 4 * kq + r, y0 = 2 * (tt / TW), x0 = 2 * (tt % TW);  // C layout of 16x16x4: row 4 (lane >> 4) + r, column lane & 15
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float v = yo[nt][r][i][c] + bv;
+                    if (tt < NTL && y0 + i < CH && x0 + c < CW) act[(nt * 16 + m) * PS + (y0 + i) * CW + x0 + c] = v > 0.0f ? v : 0.0f;
+                }
+        }
+    }
+}
+
 template <int CH, int CW>
 struct TrunkGeom {
     static constexpr int P1 = CH * CW, PW = CW + 2, PH = CH + 2;
@@ -173,7 +296,7 @@ struct TrunkGeom {
 //   inp : (CH+2)x(CW+2) zero-padded input plane        act : [32 ch][PS] planes, conv1 -> conv2 -> conv3 outputs
 // 8.8 KB of LDS per wave -> four 4-wave blocks per CU, i.e. four waves per SIMD: the MFMA pipe always has
 // another wave's k-steps to run while one wave is in a load / store / conv1 phase.
-template <int CH, int CW>
+template <int CH, int CW, bool WINO>
 __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, TrunkParams tp, float *__restrict__ feat) {
     using G = TrunkGeom<CH, CW>;
     if (dyn_count) { int c = *dyn_count; B = c < B ? c : B; }  // rows actually filled this step
@@ -184,6 +307,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, 
     float *inp = smem + wave * G::WAVE_FLOATS;
     float *act = inp + G::INP;
     for (int i = lane; i < G::INP; i += 64) inp[i] = 0.0f;
+    if (WINO && lane < NCH) act[lane * G::PS + G::P1] = 0.0f;  // every plane's zero slot: where the Winograd patches read outside the plane
     LDS_FENCE();
     for (int p = lane; p < G::P1; p += 64) inp[(p / CW + 1) * G::PW + (p % CW) + 1] = in[(size_t)b * G::P1 + p];
     LDS_FENCE();
@@ -210,7 +334,9 @@ __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, 
         store_relu_lds<G::P1, G::PS, G::MT2>(act, lane, acc);
     }
     LDS_FENCE();
-    {  // conv2 32->32, pad 1 (othello.py:371)
+    if constexpr (WINO) {  // conv2 32->32, pad 1 (othello.py:371), Winograd form
+        conv2_wino<CH, CW, G::PS>(act, tp.wu, tp.cb[0], lane);
+    } else {  // conv2 32->32, pad 1 (othello.py:371)
         f32x4 acc[G::MT2][2];
         conv_mfma<G::P1, CW, CH, CW, G::PS, 1, G::MT2>(act, tp.wq[0], tp.cb[0], lane, acc);
         LDS_FENCE();
@@ -407,7 +533,7 @@ AZ_D void conv_epilogue(int lane, const f32x16 (&acc)[ConvPlan<P_OUT>::MTA], con
 // start.  Measured on MI355X, 16384 boards: the MFMA pipes are busy 87 % of the 325 us (the rest: the younger wave
 // of each SIMD runs ~40 % slower than the older one while they share the pipe and finishes its last pair alone;
 // s_setprio can swap the roles but not level them).
-template <int CH, int CW, int WPB>
+template <int CH, int CW, int WPB, bool WINO>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_trunk2(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, TrunkParams tp, float *__restrict__ feat) {
     using G = TrunkGeom<CH, CW>;
     using PL2 = ConvPlan<G::P1>;
@@ -468,8 +594,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
     if (PL2::R16) { bq2[0] = tp.cb[0][lane & 15]; bq2[1] = tp.cb[0][16 + (lane & 15)]; }
     if (PL3::R16) { bq3[0] = tp.cb[1][lane & 15]; bq3[1] = tp.cb[1][16 + (lane & 15)]; }
     if (PL4::R16) { bq4[0] = tp.cb[2][lane & 15]; bq4[1] = tp.cb[2][16 + (lane & 15)]; }
-    LOAD_W0(0)
-    LOAD_W16(0, PL2)
+    if (!WINO) {
+        LOAD_W0(0)
+        LOAD_W16(0, PL2)
+    }
     float *inp = smem + 16 + wave * 2 * G::WAVE_FLOATS;  // 64 bytes in front hold the queues
     float *act = inp + G::INP;
     for (int i = lane; i < 2 * G::WAVE_FLOATS; i += 64) if (i % G::WAVE_FLOATS < G::INP) inp[i] = 0.0f;
@@ -527,7 +655,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
                 }
         }
         LDS_FENCE();
-        {  // conv2 32->32, pad 1
+        if constexpr (WINO) {  // conv2 32->32, pad 1, Winograd form: one board after the other (a board's tiles fill a 16-row MFMA tile)
+            conv2_wino<CH, CW, G::PS>(act, tp.wu, tp.cb[0], ln);
+            conv2_wino<CH, CW, G::PS>(act + OFF1, tp.wu, tp.cb[0], ln);
+            LOAD_W0(1)
+            LOAD_W16(1, PL3)
+        } else {  // conv2 32->32, pad 1
             f32x16 acc[PL2::MTA];
             f32x4 acc16[2];
             conv32<G::P1, CW, CH, CW, G::PS, OFF1, 1>(act, tp.wp[0], tp.wq[0], bv2, bq2, w0, w16, ln, acc, acc16);
@@ -551,8 +684,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
             f32x16 acc[PL4::MTA];
             f32x4 acc16[2];
             conv32<G::P4, G::W4, G::H4, G::W3, G::PS, OFF1, 0>(act, tp.wp[2], tp.wq[2], bv4, bq4, w0, w16, ln, acc, acc16);
-            LOAD_W0(0)
-            LOAD_W16(0, PL2)
+            if (!WINO) {
+                LOAD_W0(0)
+                LOAD_W16(0, PL2)
+            }
             if constexpr (G::P4 % 4 == 0 && !PL4::R16) {
                 // registers 4g .. 4g+3 of a tile are four consecutive positions of one board: one 16-byte store each
 #pragma unroll
@@ -1341,6 +1476,7 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
         for (int l = 0; l < 3; ++l) { NA(n->tp.cb[l], NCH) }
         NA(n->tp.w1p, 5 * 64)
         for (int l = 0; l < 3; ++l) { NA(n->tp.wp[l], 9 * 16 * 64) NA(n->tp.wq[l], 9 * 16 * 64) }
+        NA(n->tp.wu, 2 * 8 * 4 * 64 * 4)
         NA(n->fc1w, (size_t)n->FIN * n->F1) NA(n->fc1b, n->F1) NA(n->fc2w, (size_t)n->F1 * n->F2) NA(n->fc2b, n->F2)
         NA(n->hw, (size_t)n->F2 * n->NH) NA(n->hb, n->NH) NA(n->hwq, (size_t)n->F2 * n->NH)
         NA(n->feat, (size_t)max_batch * n->FIN) NA(n->h1, (size_t)max_batch * n->F1) NA(n->h2, (size_t)max_batch * n->F2)
@@ -1487,6 +1623,28 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
                             fp[((t * 4 + i / 4) * 64 + lane) * 4 + i % 4] = (float)((double)(*w)[(oc * NCH + ic) * 9 + t] * s[oc]);
                         }
             AZ_TRY(upload((float *)n->tp.wq[l - 1], fp, st));
+            if (l == 1) {
+                // conv2 in the Winograd F(2x2,3x3) form: U[f = 4 i + jj][ic][oc] = (G g' G^T)[i][jj], g' = w * s, all in float64, rounded
+                // once; stored as 16x16x4 B fragments [pass p][k-step j][e / 4][lane][e % 4], e = 2 f8 + nt, f = 8 p + f8:
+                // lane (n = lane & 15, kq = lane >> 4) holds U[f][ic = 4 j + kq][oc = 16 nt + n]
+                static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+                std::vector<float> fu(2 * 8 * 4 * 64 * 4);
+                for (int pp = 0; pp < 2; ++pp)
+                    for (int j = 0; j < 8; ++j)
+                        for (int e = 0; e < 16; ++e)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int f = 8 * pp + e / 2, nt = e % 2, oc = 16 * nt + (lane & 15), ic = 4 * j + (lane >> 4);
+                                const int fi = f / 4, fj = f % 4;
+                                double t3[3];
+                                for (int b = 0; b < 3; ++b) {
+                                    const double g0 = (double)(*w)[(oc * NCH + ic) * 9 + 0 * 3 + b] * s[oc], g1 = (double)(*w)[(oc * NCH + ic) * 9 + 1 * 3 + b] * s[oc],
+                                                 g2 = (double)(*w)[(oc * NCH + ic) * 9 + 2 * 3 + b] * s[oc];
+                                    t3[b] = (G[fi][0] * g0 + G[fi][1] * g1) + G[fi][2] * g2;
+                                }
+                                fu[(((size_t)(pp * 8 + j) * 4 + e / 4) * 64 + lane) * 4 + e % 4] = (float)((t3[0] * G[fj][0] + t3[1] * G[fj][1]) + t3[2] * G[fj][2]);
+                            }
+                AZ_TRY(upload((float *)n->tp.wu, fu, st));
+            }
         }
     }
     {
@@ -1538,7 +1696,7 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
 // trainer.py:383-387): one thread per destination element, float64 arithmetic in the host code's operation order
 // (no contraction), so both paths produce identical bits.
 // ---------------------------------------------------------------------------------------------
-enum { FOLD_BIAS = 0, FOLD_W1F, FOLD_W1P, FOLD_WP, FOLD_WQ, FOLD_DENSE_T, FOLD_HEADS_W, FOLD_HEADS_WQ, FOLD_HEADS_B };
+enum { FOLD_BIAS = 0, FOLD_W1F, FOLD_W1P, FOLD_WP, FOLD_WQ, FOLD_WINO, FOLD_DENSE_T, FOLD_HEADS_W, FOLD_HEADS_WQ, FOLD_HEADS_B };
 struct FoldJob {
     int mode, n_dst, K, N, A;
     const float *w, *b, *g, *beta, *mean, *var;  // w: the layer's weight (heads: fc_probs.weight), b: bias (heads: fc_value.*)
@@ -1574,6 +1732,20 @@ __global__ void k_fold(FoldJob j) {
             const int r = i % 4, lane = (i / 4) % 64, q = (i / 256) % 4, t = i / 1024;
             const int f = 4 * q + r, j8 = f / 2, nt = f % 2, oc = nt * 16 + (lane & 15), ic = 4 * j8 + (lane >> 4);
             out = (float)((double)j.w[(oc * NCH + ic) * 9 + t] * fold_scale(j, oc));
+            break;
+        }
+        case FOLD_WINO: {  // conv2 Winograd fragments (see az_net_commit): [p][j][e / 4][lane][e % 4]
+            const int r = i % 4, lane = (i / 4) % 64, q = (i / 256) % 4, jj8 = (i / 1024) % 8, pp = i / 8192;
+            const int e = 4 * q + r, f = 8 * pp + e / 2, nt = e % 2, oc = 16 * nt + (lane & 15), ic = 4 * jj8 + (lane >> 4), fi = f / 4, fj = f % 4;
+            const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            const double sc = fold_scale(j, oc);
+            double t3[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const double g0 = (double)j.w[(oc * NCH + ic) * 9 + b] * sc, g1 = (double)j.w[(oc * NCH + ic) * 9 + 3 + b] * sc, g2 = (double)j.w[(oc * NCH + ic) * 9 + 6 + b] * sc;
+                t3[b] = (G[fi][0] * g0 + G[fi][1] * g1) + G[fi][2] * g2;
+            }
+            out = (float)((t3[0] * G[fj][0] + t3[1] * G[fj][1]) + t3[2] * G[fj][2]);
             break;
         }
         case FOLD_DENSE_T: {  // dst[k][n] = W[n][k] * s[n]
@@ -1665,6 +1837,7 @@ extern "C" int az_net_commit_device(az_net *n, void *stream) {
             AZ_TRY(fold_launch(n, FOLD_BIAS, (float *)n->tp.cb[l - 1], NCH, "", 0, cn + ".bias", NCH, bnn, NCH, 0, 0, 0, st));
             AZ_TRY(fold_launch(n, FOLD_WP, (float *)n->tp.wp[l - 1], 9 * 16 * 64, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
             AZ_TRY(fold_launch(n, FOLD_WQ, (float *)n->tp.wq[l - 1], 9 * 16 * 64, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
+            if (l == 1) AZ_TRY(fold_launch(n, FOLD_WINO, (float *)n->tp.wu, 2 * 8 * 4 * 64 * 4, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
         }
     }
     AZ_TRY(fold_launch(n, FOLD_DENSE_T, n->fc1w, n->FIN * n->F1, "fc1.weight", (size_t)n->F1 * n->FIN, "", 0, "fc_bn1", n->F1, n->FIN, n->F1, 0, st));
@@ -1680,7 +1853,19 @@ extern "C" int az_net_commit_device(az_net *n, void *stream) {
     return AZ_OK;
 }
 
-template <int CH, int CW>
+// EXPERIMENTAL, off by default: AZ_WINOGRAD=1 (read here AND by the oracle, so that the two stay bit-equal) runs conv2 in the
+// Winograd F(2x2,3x3) form on 8x8 and 7x6 planes.  It is exact to the same 5e-7 as the direct form against the reference's
+// torch forward and bit-equal to its oracle restatement, but it does not pay on this layout (MI355X, 32768 / 8192 boards:
+// 518 vs 525 us for 8x8, 122 vs 104 us for 7x6): a 16-row tile consumes one 256-byte U fragment per 32-cycle MFMA -- 8x the
+// weight stream of the direct form per MFMA cycle, all of it from L2 (446 us with the stream removed); U (64 KB) would have
+// to live in LDS, which the two boards per wave of k_trunk2 leave no room for on 8x8 planes.  See DESIGN.md.
+static bool use_wino(int CH, int CW) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("AZ_WINOGRAD"); on = (e && atoi(e)) ? 1 : 0; }
+    return on && ((CH == 8 && CW == 8) || (CH == 7 && CW == 6));
+}
+
+template <int CH, int CW, bool WINO>
 static int launch_trunk2(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
     using G = TrunkGeom<CH, CW>;
     constexpr int WPB = 8;  // one workgroup per CU: two waves per SIMD, two boards per wave
@@ -1692,22 +1877,22 @@ static int launch_trunk2(az_net *n, const float *in, int B, const int *dyn, hipS
         int dev = 0;
         AZ_HIP(hipGetDevice(&dev));
         AZ_HIP(hipGetDeviceProperties(&pr, dev));
-        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk2<CH, CW, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk2<CH, CW, WPB, WINO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         n_cu = pr.multiProcessorCount;
     }
     const int pairs = (B + 1) / 2, want = (pairs + 3) / 4;
-    hipLaunchKernelGGL((k_trunk2<CH, CW, WPB>), dim3(want < n_cu ? want : n_cu), dim3(64 * WPB), lds_bytes, st, in, B, dyn, n->tp, n->feat);
+    hipLaunchKernelGGL((k_trunk2<CH, CW, WPB, WINO>), dim3(want < n_cu ? want : n_cu), dim3(64 * WPB), lds_bytes, st, in, B, dyn, n->tp, n->feat);
     return AZ_OK;
 }
 
 static bool trunk_v1() { static int v = -1; if (v < 0) { const char *e = getenv("AZ_TRUNK_V1"); v = (e && atoi(e)) ? 1 : 0; } return v == 1; }
 
-template <int CH, int CW>
+template <int CH, int CW, bool WINO>
 static int launch_trunk(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
     // two boards per wave on 32x32x2 pays from ~4096 boards up (16384: 325 vs 331 us); below that the one-board-
     // per-wave kernel fills the chip better (2048: 45 vs 77 us).  AZ_TRUNK_V1=1 forces the latter.
     n->last_trunk_two_boards = (!trunk_v1() && B >= 4096) ? 1 : 0;
-    if (n->last_trunk_two_boards) return launch_trunk2<CH, CW>(n, in, B, dyn, st);
+    if (n->last_trunk_two_boards) return launch_trunk2<CH, CW, WINO>(n, in, B, dyn, st);
     using G = TrunkGeom<CH, CW>;
     static bool attr_set = false;
     static int lds_bytes = G::LDS_BYTES;
@@ -1717,10 +1902,10 @@ static int launch_trunk(az_net *n, const float *in, int B, const int *dyn, hipSt
         const char *e = getenv("AZ_TRUNK_BLOCKS_PER_CU");
         int want = e ? atoi(e) : 3;
         if (want >= 1 && want <= 8 && 160 * 1024 / want > G::LDS_BYTES) lds_bytes = (160 * 1024 / want) & ~15;
-        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk<CH, CW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk<CH, CW, WINO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_trunk<CH, CW>), dim3((B + 3) / 4), dim3(256), lds_bytes, st, in, B, dyn, n->tp, n->feat);
+    hipLaunchKernelGGL((k_trunk<CH, CW, WINO>), dim3((B + 3) / 4), dim3(256), lds_bytes, st, in, B, dyn, n->tp, n->feat);
     return AZ_OK;
 }
 
@@ -1862,9 +2047,9 @@ static int run_stage(az_net *n, int stage, const float *d_input, int B, const in
     if (stage >= 1 && tail_is_fused(n)) return stage == 1 ? launch_tail(n, B, d_probs, d_value, dyn, st) : AZ_OK;  // stages 2, 3 ran inside stage 1
     switch (stage) {
         case 0:
-            if (n->CH == 8 && n->CW == 8) return launch_trunk<8, 8>(n, d_input, B, dyn, st);
-            if (n->CH == 6 && n->CW == 6) return launch_trunk<6, 6>(n, d_input, B, dyn, st);
-            return launch_trunk<7, 6>(n, d_input, B, dyn, st);
+            if (n->CH == 8 && n->CW == 8) return use_wino(8, 8) ? launch_trunk<8, 8, true>(n, d_input, B, dyn, st) : launch_trunk<8, 8, false>(n, d_input, B, dyn, st);
+            if (n->CH == 6 && n->CW == 6) return launch_trunk<6, 6, false>(n, d_input, B, dyn, st);
+            return use_wino(7, 6) ? launch_trunk<7, 6, true>(n, d_input, B, dyn, st) : launch_trunk<7, 6, false>(n, d_input, B, dyn, st);
         case 1: return launch_gemm(n->feat, n->fc1w, n->fc1b, n->h1, B, n->F1, n->FIN, true, dyn, st);
         case 2: return launch_gemm(n->h1, n->fc2w, n->fc2b, n->h2, B, n->F2, n->F1, true, dyn, st);
         default: return launch_heads(n, B, d_probs, d_value, dyn, st);

@@ -394,6 +394,8 @@ struct orc_convnet {
     /* folded */
     float *cw_f[4]; /* conv1: [9][32] ; conv2-4: [9][32 ic][32 oc] */
     float *cb_f[4];
+    float *c2u;     /* conv2 for the Winograd F(2x2,3x3) form: U[16 frequencies][32 ic][32 oc] = G g' G^T (float64, rounded once) */
+    int wino;       /* conv2 runs in the Winograd form (the product's choice for this plane shape) */
     float *f1w, *f1b, *f2w, *f2b; /* [K][N] transposed for vectorisation over N */
     float *hw, *hb;               /* heads: [512][A+1] (last column = value) */
     int folded;
@@ -405,11 +407,18 @@ static float *dupf(const float *d, int64_t n) {
     return p;
 }
 
+void orc_convnet_set_winograd(orc_convnet *n, int on) { n->wino = on; }
+int orc_convnet_winograd(const orc_convnet *n) { return n->wino; }
+
 orc_convnet *orc_convnet_create(int game, int H, int W) {
     orc_convnet *n = (orc_convnet *)calloc(1, sizeof(*n));
     n->game = game; n->H = H; n->W = W;
     if (game == ORC_OTHELLO) { n->ch = H; n->cw = W; n->A = H * W + 1; n->F1 = 1024; n->F2 = 512; }
     else { n->ch = W; n->cw = H; n->A = W; n->F1 = 64; n->F2 = 32; } /* connect4.py:360-365,399 */
+    {   /* AZ_WINOGRAD=1: the product's experimental Winograd conv2 on 8x8 and 7x6 planes (off by default) -- the oracle follows */
+        const char *e = getenv("AZ_WINOGRAD");
+        n->wino = (e && atoi(e)) && ((n->ch == 8 && n->cw == 8) || (n->ch == 7 && n->cw == 6));
+    }
     n->FIN = NCH * (n->ch - 4) * (n->cw - 4);
     return n;
 }
@@ -422,7 +431,7 @@ void orc_convnet_destroy(orc_convnet *n) {
     }
     for (int i = 0; i < 2; ++i) { free(n->fbn_g[i]); free(n->fbn_b[i]); free(n->fbn_m[i]); free(n->fbn_v[i]); }
     free(n->fc1_w); free(n->fc1_b); free(n->fc2_w); free(n->fc2_b); free(n->fp_w); free(n->fp_b); free(n->fv_w); free(n->fv_b);
-    free(n->f1w); free(n->f1b); free(n->f2w); free(n->f2b); free(n->hw); free(n->hb);
+    free(n->f1w); free(n->f1b); free(n->f2w); free(n->f2b); free(n->hw); free(n->hb); free(n->c2u);
     free(n);
 }
 
@@ -482,6 +491,21 @@ int orc_convnet_fold(orc_convnet *n) {
             for (int ic = 0; ic < IC; ++ic)
                 for (int t = 0; t < 9; ++t)
                     n->cw_f[l][(t * IC + ic) * NCH + oc] = (float)((double)n->conv_w[l][(oc * IC + ic) * 9 + t] * s);
+        }
+    }
+    {   /* Winograd weights of conv2: U = G g' G^T with g' = w * s in float64, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] */
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        free(n->c2u);
+        n->c2u = (float *)malloc(sizeof(float) * 16 * NCH * NCH);
+        for (int oc = 0; oc < NCH; ++oc) {
+            double s = (double)n->bn_g[1][oc] / sqrt((double)n->bn_v[1][oc] + BN_EPS);
+            for (int ic = 0; ic < NCH; ++ic) {
+                double g[3][3], t[4][3];
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) g[a][b] = (double)n->conv_w[1][(oc * NCH + ic) * 9 + a * 3 + b] * s;
+                for (int i = 0; i < 4; ++i) for (int b = 0; b < 3; ++b) t[i][b] = (G[i][0] * g[0][b] + G[i][1] * g[1][b]) + G[i][2] * g[2][b];
+                for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j)
+                    n->c2u[((i * 4 + j) * NCH + ic) * NCH + oc] = (float)((t[i][0] * G[j][0] + t[i][1] * G[j][1]) + t[i][2] * G[j][2]);
+            }
         }
     }
     free(n->f1w); free(n->f1b); free(n->f2w); free(n->f2b); free(n->hw); free(n->hb);
@@ -549,6 +573,52 @@ static void conv_layer(const float *in, int IC, int ih, int iw, int pad, const f
         }
 }
 
+/* conv2 ("same", 32 -> 32) in the Winograd F(2x2,3x3) form: the arithmetic of the HIP trunk kernels' EXPERIMENTAL conv2 path
+ * (AZ_WINOGRAD=1, 8x8 and 7x6 planes; 2.25x fewer multiplications).  Per 2x2 output tile with its zero-padded 4x4 input patch d (per input channel):
+ *   V = B^T d B      T[0]=d[0]-d[2], T[1]=d[1]+d[2], T[2]=d[2]-d[1], T[3]=d[1]-d[3] (rows), then the same on the columns of T
+ *   M[f][oc] = sum over ic ASCENDING of fmaf(V[f][ic], U[f][ic][oc], M) from 0, for each of the 16 frequencies f = 4 i + j
+ *   Y = A^T M A      first along the columns of M: R[i][0]=(M[i][0]+M[i][1])+M[i][2], R[i][1]=(M[i][1]-M[i][2])-M[i][3],
+ *                    then along the rows: Y[0][c]=(R[0][c]+R[1][c])+R[2][c], Y[1][c]=(R[1][c]-R[2][c])-R[3][c]
+ *                    (the order in which the HIP kernels, which hold frequency rows 0-1 and 2-3 in two passes, can combine them)
+ *   out = relu(Y + bias)
+ * Every line is one IEEE float32 operation in the order written. */
+static void conv2_winograd(const float *in, int ih, int iw, const float *U, const float *bias, float *out) {
+    const int th = (ih + 1) / 2, tw = (iw + 1) / 2;
+    for (int ty = 0; ty < th; ++ty)
+        for (int tx = 0; tx < tw; ++tx) {
+            float M[16][NCH];
+            for (int f = 0; f < 16; ++f) for (int oc = 0; oc < NCH; ++oc) M[f][oc] = 0.0f;
+            for (int ic = 0; ic < NCH; ++ic) {
+                float d[4][4], T[4][4], V[4][4];
+                for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) {
+                        int iy = 2 * ty - 1 + a, ix = 2 * tx - 1 + b;
+                        d[a][b] = (iy < 0 || iy >= ih || ix < 0 || ix >= iw) ? 0.0f : in[(ic * ih + iy) * iw + ix];
+                    }
+                for (int b = 0; b < 4; ++b) { T[0][b] = d[0][b] - d[2][b]; T[1][b] = d[1][b] + d[2][b]; T[2][b] = d[2][b] - d[1][b]; T[3][b] = d[1][b] - d[3][b]; }
+                for (int a = 0; a < 4; ++a) { V[a][0] = T[a][0] - T[a][2]; V[a][1] = T[a][1] + T[a][2]; V[a][2] = T[a][2] - T[a][1]; V[a][3] = T[a][1] - T[a][3]; }
+                for (int f = 0; f < 16; ++f) {
+                    const float v = V[f / 4][f % 4];
+                    const float *ur = U + (size_t)(f * NCH + ic) * NCH;
+                    for (int oc = 0; oc < NCH; ++oc) M[f][oc] = fmaf(v, ur[oc], M[f][oc]);
+                }
+            }
+            for (int oc = 0; oc < NCH; ++oc) {
+                float R[4][2], Y[2][2];
+                for (int i = 0; i < 4; ++i) {
+                    R[i][0] = (M[4 * i + 0][oc] + M[4 * i + 1][oc]) + M[4 * i + 2][oc];
+                    R[i][1] = (M[4 * i + 1][oc] - M[4 * i + 2][oc]) - M[4 * i + 3][oc];
+                }
+                for (int c = 0; c < 2; ++c) { Y[0][c] = (R[0][c] + R[1][c]) + R[2][c]; Y[1][c] = (R[1][c] - R[2][c]) - R[3][c]; }
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j) {
+                        int y = 2 * ty + i, x = 2 * tx + j;
+                        if (y < ih && x < iw) { float v = Y[i][j] + bias[oc]; out[(oc * ih + y) * iw + x] = v > 0.0f ? v : 0.0f; }
+                    }
+            }
+        }
+}
+
 /* dense layer: acc[n] = b[n]; for k ascending: acc[n] = fmaf(x[k], W[k][n], acc[n]) */
 static void dense_layer(const float *x, int K, const float *w, const float *b, int N, float *out, int relu) {
     for (int j = 0; j < N; ++j) out[j] = b[j];
@@ -582,7 +652,8 @@ void orc_convnet_forward(const orc_convnet *n, const float *input, int B, float 
     for (int b = 0; b < B; ++b) {
         const float *x = input + (size_t)b * ch * cw;
         conv_layer(x, 1, ch, cw, 1, n->cw_f[0], n->cb_f[0], a1, ch, cw);              /* othello.py:370 */
-        conv_layer(a1, NCH, ch, cw, 1, n->cw_f[1], n->cb_f[1], a2, ch, cw);           /* :371 */
+        if (n->wino) conv2_winograd(a1, ch, cw, n->c2u, n->cb_f[1], a2);               /* :371, Winograd form */
+        else conv_layer(a1, NCH, ch, cw, 1, n->cw_f[1], n->cb_f[1], a2, ch, cw);      /* :371 */
         conv_layer(a2, NCH, ch, cw, 0, n->cw_f[2], n->cb_f[2], a3, ch - 2, cw - 2);   /* :372 */
         conv_layer(a3, NCH, ch - 2, cw - 2, 0, n->cw_f[3], n->cb_f[3], a4, ch - 4, cw - 4); /* :373 */
         dense_layer(a4, n->FIN, n->f1w, n->f1b, n->F1, h1, 1);                          /* :376 (dropout off in eval) */

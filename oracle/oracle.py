@@ -88,6 +88,8 @@ def lib():
     L.orc_convnet_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.orc_convnet_folded.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
     L.orc_convnet_folded.restype = C.POINTER(C.c_float)
+    L.orc_convnet_set_winograd.argtypes = [C.c_void_p, C.c_int]
+    L.orc_convnet_winograd.argtypes = [C.c_void_p]
     L.orc_mlpnet_create.restype = C.c_void_p
     L.orc_mlpnet_destroy.argtypes = [C.c_void_p]
     L.orc_mlpnet_set_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
@@ -192,6 +194,13 @@ class ConvNet:
         v = np.zeros(B, dtype=np.float32)
         lib().orc_convnet_forward(self.h, x.ctypes.data, B, probs.ctypes.data, v.ctypes.data)
         return probs, v
+
+    def set_winograd(self, on):
+        """conv2 in the Winograd F(2x2,3x3) form (the product's experimental AZ_WINOGRAD=1 path) or as a direct convolution"""
+        lib().orc_convnet_set_winograd(self.h, 1 if on else 0)
+
+    def winograd(self):
+        return bool(lib().orc_convnet_winograd(self.h))
 
     def folded(self, name):
         n = C.c_int64()

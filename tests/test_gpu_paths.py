@@ -257,3 +257,45 @@ def test_plane_shapes_without_a_trunk_kernel_are_refused():
     assert E.lib().az_net_create(0, 5, 5, 64, C.byref(h)) == E._lib.AZ_EINVAL  # odd Othello size: the reference's ValueError
     assert E.lib().az_net_create(1, 6, 7, 64, C.byref(h)) == 0
     E.lib().az_net_destroy(h)
+
+
+def test_experimental_winograd_conv2_is_bit_equal_to_its_oracle_form():
+    """AZ_WINOGRAD=1 (read once per process by the library AND by the oracle): conv2 of 8x8 and 7x6 planes in the Winograd
+    F(2x2,3x3) form, in both trunk kernels.  Run in a child process: known answers within 1e-5 of the reference, network
+    bit-equal to the oracle's Winograd restatement at small and large batches, one self-play run sample for sample."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+from conftest import TAGS
+from oracle import oracle as O
+from alphazero_amd import engine as E
+from test_gpu_net import nets
+from test_gpu_engine import sort_samples
+for tag in ('othello8', 'connect4'):
+    game, gid, H, W, A, n = TAGS[tag]
+    fx, sd, onet, hnet = nets(tag)
+    assert onet.winograd()
+    canon = fx['grids'].astype(np.float32) * fx['players'].astype(np.float32)[:, None, None]
+    p, v = hnet.forward(torch.as_tensor(canon, device='cuda'))
+    assert np.abs(p.cpu().numpy() - fx['probs']).max() < 1e-5 and np.abs(v.cpu().numpy() - fx['v']).max() < 1e-5
+    grids, players, _ = O.random_positions(gid, H, W, 77, 40, 1500)
+    x = (grids * players[:, None]).astype(np.float32)
+    op, ov = onet.forward(x)
+    p, v = hnet.forward(torch.as_tensor(x, device='cuda'))           # < 4096 rows: one board per wave
+    assert np.array_equal(p.cpu().numpy(), op) and np.array_equal(v.cpu().numpy(), ov)
+    big = E.HipNet(gid, H, W, sd, max_batch=4100)
+    idx = (np.arange(4100) * 7 + 3) %% len(x)
+    p, v = big.forward(torch.as_tensor(x[idx], device='cuda'))      # two boards per wave
+    assert np.array_equal(p.cpu().numpy(), op[idx]) and np.array_equal(v.cpu().numpy(), ov[idx])
+    eng = E.SelfPlayEngine(gid, H, W, n_slots=8, n_sim=20, net=hnet, seed=4)
+    got = sort_samples(eng.run(8))
+    ref = O.selfplay(gid, H, W, 8, 20, ('conv', onet), seed=4)
+    assert all(np.array_equal(got[k], ref[k]) for k in ('state', 'z', 'meta', 'visits', 'pi'))
+print('winograd ok')
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AZ_WINOGRAD="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "winograd ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

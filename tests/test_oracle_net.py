@@ -73,3 +73,24 @@ def test_philox_known_answer():
     L.orc_philox4x32(0xa4093822, 0x299f31d0, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, out)
     assert list(out) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
     assert cf.philox4x32(0xa4093822, 0x299f31d0, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344) == tuple(out)
+
+
+@pytest.mark.parametrize("tag", ["othello8", "connect4"])
+def test_winograd_form_of_conv2_meets_the_reference_tolerance(tag):
+    """the oracle's restatement of the product's EXPERIMENTAL conv2 path (AZ_WINOGRAD=1: Winograd F(2x2,3x3), 2.25x fewer
+    multiplications): within the same 1e-5 of the reference's torch forward (golden G2) as the direct form, and not the
+    same bits as the direct form (the two are different arithmetic; product and oracle switch together)"""
+    import ast
+    from tools import closed_form as cf
+    game, gid, H, W, A, n = TAGS[tag]
+    fx = golden(f"net_{tag}.npz")
+    shapes = {str(k): ast.literal_eval(str(v)) for k, v in zip(fx["shape_keys"], fx["shape_vals"])}
+    sd = {k: v for k, v in cf.closed_form_state_dict(shapes).items() if not k.endswith("num_batches_tracked")}
+    net = O.ConvNet(gid, H, W, sd)
+    assert not net.winograd()  # off unless AZ_WINOGRAD=1
+    canon = fx["grids"].astype(np.float32) * fx["players"].astype(np.float32)[:, None, None]
+    p0, v0 = net.forward(canon)
+    net.set_winograd(True)
+    p1, v1 = net.forward(canon)
+    assert np.abs(p1 - fx["probs"]).max() < 1e-5 and np.abs(v1 - fx["v"]).max() < 1e-5
+    assert np.abs(p1 - p0).max() < 1e-6 and not (np.array_equal(p1, p0) and np.array_equal(v1, v0))
