@@ -192,7 +192,7 @@ class Workload:
                                "minus the calibrated cost of an empty event interval per launch",
                 "profiled_step_ms": 1e3 * dt,
                 "profiled_step_kernel_ms": {k: prof[k][0] for k in prof}, "profiled_step_launches": {k: prof[k][1] for k in prof},
-                "stage_tflops": {PROF_NAMES[i]: (fl[i] * evals / (tot_ms[i] * 1e-3) / 1e12 if tot_ms[i] > 0 else None) for i in range(4)},
+                "stage_tflops": {PROF_NAMES[i]: (fl[i] * evals / (tot_ms[i] * 1e-3) / 1e12 if tot_ms[i] > 0.05 * raw_ms[i] else None) for i in range(4)},
                 "full_batch_launch_ms": dict(zip(PROF_NAMES, full)),
                 "full_batch_tflops": {PROF_NAMES[i]: fl[i] * self.G / (full[i] * 1e-3) / 1e12 for i in range(4)},
                 "forward_tflops": sum(fl) * evals / (net_ms * 1e-3) / 1e12,
