@@ -158,6 +158,8 @@ class Workload:
         ov = self.hnet.profile_overhead_ms()  # an event-to-event interval costs this much with no kernel in it
         self.hnet.profile(False)
         fl, by = stage_flops(*self.geom), algorithmic_bytes(*self.geom)
+        if self.game == "connect4":  # fc1 + fc2 + heads are one fused launch, booked in the fc1 slot
+            fl = [fl[0], fl[1] + fl[2] + fl[3], 0, 0]
         evals = st["net_evals"]
         raw_ms = [prof[k][0] for k in PROF_NAMES]
         raw_ms[0] += prof["k_trunk"][0]  # small-batch launches of the one-board-per-wave trunk kernel
