@@ -36,9 +36,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define NCH 32
-// LDS plane stride: smallest value >= x that is 1 (mod 32) -> the 16 output channels a wave
-// instruction writes land on 16 distinct banks
-#define PLANE_STRIDE(x) ((((x) + 30) / 32) * 32 + 1)
+// LDS plane stride: the smallest ODD value > x -- the 16 / 32 output channels a wave instruction writes at one position land
+// on distinct banks (oc * PS mod 32 is a permutation for odd PS), and slot x of every plane is a spare (kept zero where a
+// kernel redirects out-of-plane reads to it).  8x8 planes: 65, 7x6: 43, 6x6: 37.
+#define PLANE_STRIDE(x) (((x) + 1) | 1)
 
 #ifdef AZ_PROBE  // diagnostic build only (make PROBE=1): per-phase shader-clock stamps of wave 0 of every block
 __device__ unsigned long long az_probe_buf[8192 * 8];
@@ -172,14 +173,15 @@ AZ_D void store_relu_lds(float *out, int lane, const f32x4 (&acc)[MT][2]) {
 // Y[1][c] = (R[1][c]-R[2][c])-R[3][c], out = relu(Y + bias): one IEEE operation per step, in this order.
 // The output overwrites the input planes (all reads are done before the first write).
 // ---------------------------------------------------------------------------------------------
-template <int CH, int CW, int PS>
-AZ_D void conv2_wino(float *act, const float *__restrict__ wu, const float *__restrict__ bias, int lane) {
+template <int CH, int CW, int PS, int RING>
+AZ_D void conv2_wino(float *act, const float4 *wu4, const float *__restrict__ bias, int lane) {
     constexpr int TW = (CW + 1) / 2, NTL = ((CH + 1) / 2) * TW, P1 = CH * CW;
     static_assert(NTL <= 16 && PS > P1, "one 16-row tile of 2x2 output tiles per board; a zero slot behind every plane");
     const int m = lane & 15, kq = lane >> 4;
     const int t = m < NTL ? m : NTL - 1;  // padding rows repeat the last tile (finite operands, never stored)
     const int ty = t / TW, tx = t % TW;
-    const float4 *ul = reinterpret_cast<const float4 *>(wu) + lane;
+    // wu4: the U fragments, in global memory (RING = 3: requested two k-steps ahead) or copied into the workgroup's LDS (RING = 2)
+    const float4 *ul = wu4 + lane;
     float cu[2][4][2], cw_[2][4][2];  // pass 0 -> pass 1: R[0][c] + R[1][c] and R[1][c] per (nt, r)
     float yo[2][4][2][2];             // Y[i][c] per (nt, r)
 #pragma unroll
@@ -195,10 +197,10 @@ AZ_D void conv2_wino(float *act, const float *__restrict__ wu, const float *__re
         f32x4 acc[8][2];
 #pragma unroll
         for (int f = 0; f < 8; ++f) { acc[f][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc[f][1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-        // U fragments: a ring of three k-steps, requested two k-steps (>= 1000 cycles of MFMA work) ahead of their use
-        float4 ub[3][4];
+        // U fragments: a ring of RING k-steps, requested RING - 1 k-steps ahead of their use
+        float4 ub[RING][4];
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < RING - 1; ++jj)
 #pragma unroll
             for (int q = 0; q < 4; ++q) ub[jj][q] = ul[(size_t)((p * 8 + jj) * 4 + q) * 64];
         float d[12];
@@ -207,9 +209,9 @@ AZ_D void conv2_wino(float *act, const float *__restrict__ wu, const float *__re
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float dn[12];
-            if (j + 2 < 8) {
+            if (j + RING - 1 < 8) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ub[(j + 2) % 3][q] = ul[(size_t)((p * 8 + j + 2) * 4 + q) * 64];
+                for (int q = 0; q < 4; ++q) ub[(j + RING - 1) % RING][q] = ul[(size_t)((p * 8 + j + RING - 1) * 4 + q) * 64];
             }
             if (j + 1 < 8) {
 #pragma unroll
@@ -229,7 +231,7 @@ AZ_D void conv2_wino(float *act, const float *__restrict__ wu, const float *__re
             __builtin_amdgcn_sched_barrier(0);  // the loads above stay issued ahead of this k-step's MFMAs
 #pragma unroll
             for (int f = 0; f < 8; ++f) {
-                const float4 u = ub[j % 3][f >> 1];
+                const float4 u = ub[j % RING][f >> 1];
                 acc[f][0] = MFMA(V[f], (f & 1) ? u.z : u.x, acc[f][0]);
                 acc[f][1] = MFMA(V[f], (f & 1) ? u.w : u.y, acc[f][1]);
             }
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, 
     }
     LDS_FENCE();
     if constexpr (WINO) {  // conv2 32->32, pad 1 (othello.py:371), Winograd form
-        conv2_wino<CH, CW, G::PS>(act, tp.wu, tp.cb[0], lane);
+        conv2_wino<CH, CW, G::PS, 3>(act, reinterpret_cast<const float4 *>(tp.wu), tp.cb[0], lane);
     } else {  // conv2 32->32, pad 1 (othello.py:371)
         f32x4 acc[G::MT2][2];
         conv_mfma<G::P1, CW, CH, CW, G::PS, 1, G::MT2>(act, tp.wq[0], tp.cb[0], lane, acc);
@@ -551,6 +553,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
     // device-wide atomic queue was far slower than the imbalance it removed (hot address: 375 us).
     int *ticket_ctr = reinterpret_cast<int *>(smem);
     if (threadIdx.x < 4) ticket_ctr[threadIdx.x] = 0;
+    // Winograd conv2 with room in LDS (7x6 planes): the 64 KB of U fragments are copied in once per (persistent) workgroup
+    // and every wave reads them from there -- a 16-row tile eats one 256-byte fragment per 32-cycle MFMA, which L2 cannot feed
+    constexpr bool ULDS = WINO && (64 + WPB * 2 * G::WAVE_FLOATS * 4 + 65536 <= 160 * 1024);
+    float4 *u_lds = reinterpret_cast<float4 *>(smem + 16 + WPB * 2 * G::WAVE_FLOATS);
+    if constexpr (ULDS) {
+        static_assert((16 + WPB * 2 * G::WAVE_FLOATS) % 4 == 0, "16-byte alignment of the U region");
+        const float4 *src = reinterpret_cast<const float4 *>(tp.wu);
+        for (int i = threadIdx.x; i < 4096; i += 64 * WPB) u_lds[i] = src[i];
+    }
     __syncthreads();  // the only workgroup barrier: the waves are independent from here on
     const int simd = (__builtin_amdgcn_s_getreg((4 << 11) | (4 << 6) | 4) & 3);  // HW_REG_HW_ID bits [5:4]
     // a wave draws from its own SIMD's queue and, once that is empty, from the other three: every pair is processed
@@ -656,8 +667,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
         }
         LDS_FENCE();
         if constexpr (WINO) {  // conv2 32->32, pad 1, Winograd form: one board after the other (a board's tiles fill a 16-row MFMA tile)
-            conv2_wino<CH, CW, G::PS>(act, tp.wu, tp.cb[0], ln);
-            conv2_wino<CH, CW, G::PS>(act + OFF1, tp.wu, tp.cb[0], ln);
+            if constexpr (ULDS) {
+                conv2_wino<CH, CW, G::PS, 2>(act, u_lds, tp.cb[0], ln);
+                conv2_wino<CH, CW, G::PS, 2>(act + OFF1, u_lds, tp.cb[0], ln);
+            } else {
+                conv2_wino<CH, CW, G::PS, 3>(act, reinterpret_cast<const float4 *>(tp.wu), tp.cb[0], ln);
+                conv2_wino<CH, CW, G::PS, 3>(act + OFF1, reinterpret_cast<const float4 *>(tp.wu), tp.cb[0], ln);
+            }
             LOAD_W0(1)
             LOAD_W16(1, PL3)
         } else {  // conv2 32->32, pad 1
@@ -1853,15 +1869,18 @@ extern "C" int az_net_commit_device(az_net *n, void *stream) {
     return AZ_OK;
 }
 
-// EXPERIMENTAL, off by default: AZ_WINOGRAD=1 (read here AND by the oracle, so that the two stay bit-equal) runs conv2 in the
-// Winograd F(2x2,3x3) form on 8x8 and 7x6 planes.  It is exact to the same 5e-7 as the direct form against the reference's
-// torch forward and bit-equal to its oracle restatement, but it does not pay on this layout (MI355X, 32768 / 8192 boards:
-// 518 vs 525 us for 8x8, 122 vs 104 us for 7x6): a 16-row tile consumes one 256-byte U fragment per 32-cycle MFMA -- 8x the
-// weight stream of the direct form per MFMA cycle, all of it from L2 (446 us with the stream removed); U (64 KB) would have
-// to live in LDS, which the two boards per wave of k_trunk2 leave no room for on 8x8 planes.  See DESIGN.md.
+// EXPERIMENTAL, off by default: AZ_WINOGRAD=1 (read here AND by the oracle, so that the two stay bit-equal) runs conv2 of 8x8
+// and 7x6 planes in the Winograd F(2x2,3x3) form (2.25x fewer multiplications; exact to the same 5e-7 as the direct form
+// against the reference's torch forward, bit-equal to its restatement in the oracle).  Measured on MI355X, it does not pay:
+//   * 8x8 planes, 32768 boards: 518 vs 525 us.  A board's 16 output tiles make a 16-row MFMA tile, which eats one 256-byte
+//     U fragment per 32-cycle MFMA -- 8x the weight stream of the direct form per MFMA cycle, all of it from L2 (446 us with
+//     the stream removed); two boards per wave leave no room for the 64 KB of U in LDS.
+//   * 7x6 planes, 8192 boards, U resident in LDS: 103 vs 101 us.  12 tiles fill the 16-row MFMA tile to 75 %, every k-step
+//     needs its operand transformed by the wave itself (12 LDS reads + 16 adds per 16 MFMAs of 32 cycles): the instruction
+//     stream, not the matrix pipe, is the limit, and the intermediate is 4x the output (64 accumulator + 32 carry registers).
 static bool use_wino(int CH, int CW) {
     static int on = -1;
-    if (on < 0) { const char *e = getenv("AZ_WINOGRAD"); on = (e && atoi(e)) ? 1 : 0; }
+    if (on < 0) { const char *e = getenv("AZ_WINOGRAD"); on = (e && atoi(e) == 1) ? 1 : 0; }
     return on && ((CH == 8 && CW == 8) || (CH == 7 && CW == 6));
 }
 
@@ -1869,7 +1888,8 @@ template <int CH, int CW, bool WINO>
 static int launch_trunk2(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
     using G = TrunkGeom<CH, CW>;
     constexpr int WPB = 8;  // one workgroup per CU: two waves per SIMD, two boards per wave
-    constexpr int lds_bytes = 64 + WPB * 2 * G::WAVE_FLOATS * 4;
+    constexpr int lds_planes = 64 + WPB * 2 * G::WAVE_FLOATS * 4;
+    constexpr int lds_bytes = lds_planes + ((WINO && lds_planes + 65536 <= 160 * 1024) ? 65536 : 0);  // + the Winograd U fragments where they fit
     static_assert(lds_bytes <= 160 * 1024, "k_trunk2 workgroup does not fit the CU's LDS");
     static int n_cu = 0;
     if (!n_cu) {

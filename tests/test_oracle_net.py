@@ -77,7 +77,7 @@ def test_philox_known_answer():
 
 @pytest.mark.parametrize("tag", ["othello8", "connect4"])
 def test_winograd_form_of_conv2_meets_the_reference_tolerance(tag):
-    """the oracle's restatement of the product's EXPERIMENTAL conv2 path (AZ_WINOGRAD=1: Winograd F(2x2,3x3), 2.25x fewer
+    """the oracle's restatement of the product's EXPERIMENTAL Winograd conv2 path (AZ_WINOGRAD=1: F(2x2,3x3), 2.25x fewer
     multiplications): within the same 1e-5 of the reference's torch forward (golden G2) as the direct form, and not the
     same bits as the direct form (the two are different arithmetic; product and oracle switch together)"""
     import ast
@@ -89,6 +89,7 @@ def test_winograd_form_of_conv2_meets_the_reference_tolerance(tag):
     net = O.ConvNet(gid, H, W, sd)
     assert not net.winograd()  # off unless AZ_WINOGRAD=1
     canon = fx["grids"].astype(np.float32) * fx["players"].astype(np.float32)[:, None, None]
+    net.set_winograd(False)
     p0, v0 = net.forward(canon)
     net.set_winograd(True)
     p1, v1 = net.forward(canon)
