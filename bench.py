@@ -313,10 +313,10 @@ def main():
     per_rank_all = per_rank.clone().view(1, 2)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per_rank_all = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+        per_rank_all = torch.zeros(world * 2, dtype=torch.float64, device=dev)  # flat: the one layout every backend concatenates alike
         dist.all_gather_into_tensor(per_rank_all, per_rank)
     dt = float(t.item())
-    per_rank_all = per_rank_all.cpu().numpy()
+    per_rank_all = per_rank_all.view(-1, 2).cpu().numpy()
     st = w.eng.stats()
 
     if rank == 0:
