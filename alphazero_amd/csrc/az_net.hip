@@ -34,6 +34,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 #define NCH 32
 // LDS plane stride: the smallest ODD value > x -- the 16 / 32 output channels a wave instruction writes at one position land
@@ -56,6 +58,7 @@ struct TrunkParams {
     const float *wq[3];          // conv2..4, 16x16x4 B fragments (k_trunk; k_trunk2's 16-row tiles): [9 taps][4][64 lanes][4] (fragment i = 2 j + nt)
     const float *wu;             // conv2 in the Winograd F(2x2,3x3) form: U = G g' G^T as 16x16x4 B fragments
                                  // [2 passes][8 k-steps][4][64 lanes][4]: fragment e = 2 f8 + nt of frequency f = 8 p + f8
+    const float *wu32;           // the same U as 32x32x2 B fragments [4][16 frequencies][64 lanes][4 k-steps] (conv2_wino32)
 };
 
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -157,7 +160,7 @@ AZ_D void store_relu_lds(float *out, int lane, const f32x4 (&acc)[MT][2]) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// EXPERIMENTAL (AZ_WINOGRAD=1, see use_wino): conv2 ("same", 32 -> 32) of ONE board in the Winograd F(2x2,3x3) form: 2.25x
+// conv2 ("same", 32 -> 32) of ONE board in the Winograd F(2x2,3x3) form: 2.25x
 // fewer multiplications than the direct form (conv2 is 54 % of the trunk's work).  The board's 2x2 output tiles are the rows of a 16x16x4 MFMA tile (8x8 plane:
 // 16 tiles, 7x6: 12), and for each of the 16 "frequencies" f = 4 i + j the products over the input channels are one
 // k-ordered MFMA chain:   M[f][tile][oc] = sum over ic ascending of V[f][tile][ic] * U[f][ic][oc]      (from 0)
@@ -278,6 +281,96 @@ AZ_D void conv2_wino(float *act, const float4 *wu4, const float *__restrict__ bi
     }
 }
 
+// The same Winograd conv2 for BOTH boards of a wave at once on v_mfma_f32_32x32x2_f32: the 2 x 16 output tiles of two 8x8
+// boards are the 32 rows of one MFMA tile, so a U fragment feeds 64 cycles of matrix work (half the fragment rate of the
+// 16-row form) and comes from LDS.  All 16 frequency accumulators are live at once (256 registers): this form runs in the
+// one-wave-per-SIMD variant of k_trunk2 (4 waves per workgroup, 512 registers per wave).  Same chains (ic ascending per
+// frequency, from 0), same transforms, same operation order as conv2_wino and the oracle: identical bits.
+//   u4: [jq (4)][f (16)][lane (64)] float4 = k-steps 4 jq .. 4 jq + 3 of frequency f: U[f][ic = 2 j + (lane >> 5)][oc = lane & 31]
+template <int CH, int CW, int PS, int OFF1>
+AZ_D void conv2_wino32(float *act, const float4 *u4, const float *__restrict__ bias, int lane) {
+    constexpr int TW = (CW + 1) / 2, NTL = ((CH + 1) / 2) * TW, P1 = CH * CW;
+    static_assert(2 * NTL <= 32 && PS > P1, "the tiles of two boards fill one 32-row MFMA tile");
+    const int m = lane & 31, kk = lane >> 5;
+    const int mc = m < 2 * NTL ? m : 2 * NTL - 1;  // padding rows repeat the last tile (never stored)
+    const int bd = mc / NTL, t = mc % NTL, ty = t / TW, tx = t % TW;
+    int off[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int iy = 2 * ty - 1 + a, ix = 2 * tx - 1 + b;
+            off[a * 4 + b] = bd * OFF1 + kk * PS + ((iy >= 0 && iy < CH && ix >= 0 && ix < CW) ? iy * CW + ix : P1);
+        }
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[f][i] = 0.0f;
+    const float4 *ul = u4 + lane;
+    float d[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d[e] = act[off[e]];
+    float4 ub[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) ub[f] = ul[f * 64];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float T[4][4], V[16];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { T[0][b] = d[b] - d[8 + b]; T[1][b] = d[4 + b] + d[8 + b]; T[2][b] = d[8 + b] - d[4 + b]; T[3][b] = d[4 + b] - d[12 + b]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            V[4 * i + 0] = T[i][0] - T[i][2]; V[4 * i + 1] = T[i][1] + T[i][2];
+            V[4 * i + 2] = T[i][2] - T[i][1]; V[4 * i + 3] = T[i][1] - T[i][3];
+        }
+        if (j + 1 < 16) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d[e] = act[off[e] + 2 * (j + 1) * PS];
+        }
+        float bcur[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) bcur[f] = (j % 4 == 0) ? ub[f].x : ((j % 4 == 1) ? ub[f].y : ((j % 4 == 2) ? ub[f].z : ub[f].w));
+        if (j % 4 == 3 && j + 1 < 16) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f) ub[f] = ul[((j + 1) / 4 * 16 + f) * 64];
+        }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[f] = MFMA32(V[f], bcur[f], acc[f]);
+#pragma unroll
+        for (int f = 0; f < 16; ++f) asm volatile("" : "+a"(acc[f]));
+        // one wave per SIMD: nothing else fills the matrix pipe, so the next k-step's LDS reads and transform are spread
+        // between this k-step's MFMAs (1 MFMA, 2 VALU, 2 LDS reads, 16 times)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+    }
+    LDS_FENCE();  // every read of the input planes has returned: the output may overwrite them
+    const float bv = bias[m];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = 8 * (i / 4) + 4 * kk + (i % 4);  // C layout of 32x32x2: this register's row (tile), column lane & 31
+        const int rb = r / NTL, rt = r % NTL, y0 = 2 * (rt / TW), x0 = 2 * (rt % TW);
+        float R[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            R[q][0] = (acc[4 * q + 0][i] + acc[4 * q + 1][i]) + acc[4 * q + 2][i];
+            R[q][1] = (acc[4 * q + 1][i] - acc[4 * q + 2][i]) - acc[4 * q + 3][i];
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float y0v = ((R[0][c] + R[1][c]) + R[2][c]) + bv, y1v = ((R[1][c] - R[2][c]) - R[3][c]) + bv;
+            if (r < 2 * NTL && x0 + c < CW) {
+                if (y0 < CH) act[rb * OFF1 + m * PS + y0 * CW + x0 + c] = y0v > 0.0f ? y0v : 0.0f;
+                if (y0 + 1 < CH) act[rb * OFF1 + m * PS + (y0 + 1) * CW + x0 + c] = y1v > 0.0f ? y1v : 0.0f;
+            }
+        }
+    }
+}
+
 template <int CH, int CW>
 struct TrunkGeom {
     static constexpr int P1 = CH * CW, PW = CW + 2, PH = CH + 2;
@@ -377,8 +470,6 @@ __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, 
 // uses the MFMA shape that sustains the higher rate on this chip.  Accumulation order per output is unchanged
 // (bias, then tap-major / ic-minor), so results stay bit-identical.
 // ---------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define A_RING2 3
 
 // Tiling of a layer's 2 x P_OUT output rows: MT tiles of 32 rows on 32x32x2 and, when at most 16 rows are left
@@ -536,7 +627,7 @@ AZ_D void conv_epilogue(int lane, const f32x16 (&acc)[ConvPlan<P_OUT>::MTA], con
 // of each SIMD runs ~40 % slower than the older one while they share the pipe and finishes its last pair alone;
 // s_setprio can swap the roles but not level them).
 template <int CH, int CW, int WPB, bool WINO>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_trunk2(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, TrunkParams tp, float *__restrict__ feat) {
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, WPB == 4 ? 1 : 2))) void k_trunk2(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, TrunkParams tp, float *__restrict__ feat) {
     using G = TrunkGeom<CH, CW>;
     using PL2 = ConvPlan<G::P1>;
     using PL3 = ConvPlan<G::P3>;
@@ -559,7 +650,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
     float4 *u_lds = reinterpret_cast<float4 *>(smem + 16 + WPB * 2 * G::WAVE_FLOATS);
     if constexpr (ULDS) {
         static_assert((16 + WPB * 2 * G::WAVE_FLOATS) % 4 == 0, "16-byte alignment of the U region");
-        const float4 *src = reinterpret_cast<const float4 *>(tp.wu);
+        const float4 *src = reinterpret_cast<const float4 *>(WPB == 4 ? tp.wu32 : tp.wu);  // one wave per SIMD: the 32-row form
         for (int i = threadIdx.x; i < 4096; i += 64 * WPB) u_lds[i] = src[i];
     }
     __syncthreads();  // the only workgroup barrier: the waves are independent from here on
@@ -667,7 +758,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 2))
         }
         LDS_FENCE();
         if constexpr (WINO) {  // conv2 32->32, pad 1, Winograd form: one board after the other (a board's tiles fill a 16-row MFMA tile)
-            if constexpr (ULDS) {
+            if constexpr (ULDS && WPB == 4) {
+                conv2_wino32<CH, CW, G::PS, OFF1>(act, u_lds, tp.cb[0], ln);
+            } else if constexpr (ULDS) {
                 conv2_wino<CH, CW, G::PS, 2>(act, u_lds, tp.cb[0], ln);
                 conv2_wino<CH, CW, G::PS, 2>(act + OFF1, u_lds, tp.cb[0], ln);
             } else {
@@ -1492,7 +1585,7 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
         for (int l = 0; l < 3; ++l) { NA(n->tp.cb[l], NCH) }
         NA(n->tp.w1p, 5 * 64)
         for (int l = 0; l < 3; ++l) { NA(n->tp.wp[l], 9 * 16 * 64) NA(n->tp.wq[l], 9 * 16 * 64) }
-        NA(n->tp.wu, 2 * 8 * 4 * 64 * 4)
+        NA(n->tp.wu, 2 * 8 * 4 * 64 * 4) NA(n->tp.wu32, 4 * 16 * 64 * 4)
         NA(n->fc1w, (size_t)n->FIN * n->F1) NA(n->fc1b, n->F1) NA(n->fc2w, (size_t)n->F1 * n->F2) NA(n->fc2b, n->F2)
         NA(n->hw, (size_t)n->F2 * n->NH) NA(n->hb, n->NH) NA(n->hwq, (size_t)n->F2 * n->NH)
         NA(n->feat, (size_t)max_batch * n->FIN) NA(n->h1, (size_t)max_batch * n->F1) NA(n->h2, (size_t)max_batch * n->F2)
@@ -1660,6 +1753,22 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
                                 fu[(((size_t)(pp * 8 + j) * 4 + e / 4) * 64 + lane) * 4 + e % 4] = (float)((t3[0] * G[fj][0] + t3[1] * G[fj][1]) + t3[2] * G[fj][2]);
                             }
                 AZ_TRY(upload((float *)n->tp.wu, fu, st));
+                // and as 32x32x2 B fragments [jq][f][lane][i]: k-step j = 4 jq + i, lane (oc = lane & 31, kk = lane >> 5) holds U[f][ic = 2 j + kk][oc]
+                std::vector<float> fv(4 * 16 * 64 * 4);
+                for (int jq = 0; jq < 4; ++jq)
+                    for (int f = 0; f < 16; ++f)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 4; ++i) {
+                                const int oc = lane & 31, ic = 2 * (4 * jq + i) + (lane >> 5), fi = f / 4, fj = f % 4;
+                                double t3[3];
+                                for (int b = 0; b < 3; ++b) {
+                                    const double g0 = (double)(*w)[(oc * NCH + ic) * 9 + 0 * 3 + b] * s[oc], g1 = (double)(*w)[(oc * NCH + ic) * 9 + 1 * 3 + b] * s[oc],
+                                                 g2 = (double)(*w)[(oc * NCH + ic) * 9 + 2 * 3 + b] * s[oc];
+                                    t3[b] = (G[fi][0] * g0 + G[fi][1] * g1) + G[fi][2] * g2;
+                                }
+                                fv[(((size_t)jq * 16 + f) * 64 + lane) * 4 + i] = (float)((t3[0] * G[fj][0] + t3[1] * G[fj][1]) + t3[2] * G[fj][2]);
+                            }
+                AZ_TRY(upload((float *)n->tp.wu32, fv, st));
             }
         }
     }
@@ -1712,7 +1821,7 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
 // trainer.py:383-387): one thread per destination element, float64 arithmetic in the host code's operation order
 // (no contraction), so both paths produce identical bits.
 // ---------------------------------------------------------------------------------------------
-enum { FOLD_BIAS = 0, FOLD_W1F, FOLD_W1P, FOLD_WP, FOLD_WQ, FOLD_WINO, FOLD_DENSE_T, FOLD_HEADS_W, FOLD_HEADS_WQ, FOLD_HEADS_B };
+enum { FOLD_BIAS = 0, FOLD_W1F, FOLD_W1P, FOLD_WP, FOLD_WQ, FOLD_WINO, FOLD_WINO32, FOLD_DENSE_T, FOLD_HEADS_W, FOLD_HEADS_WQ, FOLD_HEADS_B };
 struct FoldJob {
     int mode, n_dst, K, N, A;
     const float *w, *b, *g, *beta, *mean, *var;  // w: the layer's weight (heads: fc_probs.weight), b: bias (heads: fc_value.*)
@@ -1753,6 +1862,20 @@ __global__ void k_fold(FoldJob j) {
         case FOLD_WINO: {  // conv2 Winograd fragments (see az_net_commit): [p][j][e / 4][lane][e % 4]
             const int r = i % 4, lane = (i / 4) % 64, q = (i / 256) % 4, jj8 = (i / 1024) % 8, pp = i / 8192;
             const int e = 4 * q + r, f = 8 * pp + e / 2, nt = e % 2, oc = 16 * nt + (lane & 15), ic = 4 * jj8 + (lane >> 4), fi = f / 4, fj = f % 4;
+            const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            const double sc = fold_scale(j, oc);
+            double t3[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const double g0 = (double)j.w[(oc * NCH + ic) * 9 + b] * sc, g1 = (double)j.w[(oc * NCH + ic) * 9 + 3 + b] * sc, g2 = (double)j.w[(oc * NCH + ic) * 9 + 6 + b] * sc;
+                t3[b] = (G[fi][0] * g0 + G[fi][1] * g1) + G[fi][2] * g2;
+            }
+            out = (float)((t3[0] * G[fj][0] + t3[1] * G[fj][1]) + t3[2] * G[fj][2]);
+            break;
+        }
+        case FOLD_WINO32: {  // the same U as 32x32x2 fragments [jq][f][lane][i]
+            const int ii = i % 4, lane = (i / 4) % 64, f = (i / 256) % 16, jq = i / 4096;
+            const int oc = lane & 31, ic = 2 * (4 * jq + ii) + (lane >> 5), fi = f / 4, fj = f % 4;
             const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
             const double sc = fold_scale(j, oc);
             double t3[3];
@@ -1854,6 +1977,7 @@ extern "C" int az_net_commit_device(az_net *n, void *stream) {
             AZ_TRY(fold_launch(n, FOLD_WP, (float *)n->tp.wp[l - 1], 9 * 16 * 64, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
             AZ_TRY(fold_launch(n, FOLD_WQ, (float *)n->tp.wq[l - 1], 9 * 16 * 64, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
             if (l == 1) AZ_TRY(fold_launch(n, FOLD_WINO, (float *)n->tp.wu, 2 * 8 * 4 * 64 * 4, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
+            if (l == 1) AZ_TRY(fold_launch(n, FOLD_WINO32, (float *)n->tp.wu32, 4 * 16 * 64 * 4, cn + ".weight", wn, "", 0, bnn, NCH, 0, 0, 0, st));
         }
     }
     AZ_TRY(fold_launch(n, FOLD_DENSE_T, n->fc1w, n->FIN * n->F1, "fc1.weight", (size_t)n->F1 * n->FIN, "", 0, "fc_bn1", n->F1, n->FIN, n->F1, 0, st));
@@ -1869,25 +1993,31 @@ extern "C" int az_net_commit_device(az_net *n, void *stream) {
     return AZ_OK;
 }
 
-// EXPERIMENTAL, off by default: AZ_WINOGRAD=1 (read here AND by the oracle, so that the two stay bit-equal) runs conv2 of 8x8
-// and 7x6 planes in the Winograd F(2x2,3x3) form (2.25x fewer multiplications; exact to the same 5e-7 as the direct form
-// against the reference's torch forward, bit-equal to its restatement in the oracle).  Measured on MI355X, it does not pay:
-//   * 8x8 planes, 32768 boards: 518 vs 525 us.  A board's 16 output tiles make a 16-row MFMA tile, which eats one 256-byte
-//     U fragment per 32-cycle MFMA -- 8x the weight stream of the direct form per MFMA cycle, all of it from L2 (446 us with
-//     the stream removed); two boards per wave leave no room for the 64 KB of U in LDS.
-//   * 7x6 planes, 8192 boards, U resident in LDS: 103 vs 101 us.  12 tiles fill the 16-row MFMA tile to 75 %, every k-step
-//     needs its operand transformed by the wave itself (12 LDS reads + 16 adds per 16 MFMAs of 32 cycles): the instruction
-//     stream, not the matrix pipe, is the limit, and the intermediate is 4x the output (64 accumulator + 32 carry registers).
+// conv2 in the Winograd F(2x2,3x3) form (2.25x fewer multiplications; exact to the same 5e-7 as the direct form against the
+// reference's torch forward; bit-equal to its restatement in the oracle, which reads the same switch AZ_WINOGRAD):
+//   * 8x8 planes: ON.  From 4096 boards up both boards of a wave form one 32-row MFMA tile (conv2_wino32) in the
+//     one-wave-per-SIMD variant of k_trunk2: 512 registers hold all 16 frequency accumulators, the LDS the other four waves
+//     would use holds the transformed weights.  MI355X: 473 vs 526 us at 32768 boards, 71 vs 80 us at 4096.  Below 4096
+//     boards k_trunk runs the 16-row form (conv2_wino; same chains, same bits): 21 vs 23 us at 1024 boards.
+//   * 7x6 planes: OFF (AZ_WINOGRAD=1 enables it).  12 tiles per board fill a 16-row tile to 75 %; with 16-row tiles every
+//     32-cycle MFMA needs an operand transformed by the wave itself and a 256-byte weight fragment: the instruction stream,
+//     not the matrix pipe, is the limit -- 103 vs 101 us at 8192 boards even with the weights resident in LDS.  (The 16-row
+//     form on 8x8 planes in the two-waves-per-SIMD kernel: 518 vs 525 us, bound by the weight stream from L2.)
+//   * 6x6 planes: never (9 tiles per board would leave the MFMA tile 44 % empty).
+// AZ_WINOGRAD=0 switches everything back to the direct form.
 static bool use_wino(int CH, int CW) {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("AZ_WINOGRAD"); on = (e && atoi(e) == 1) ? 1 : 0; }
-    return on && ((CH == 8 && CW == 8) || (CH == 7 && CW == 6));
+    static int mode = -2;
+    if (mode == -2) { const char *e = getenv("AZ_WINOGRAD"); mode = e ? atoi(e) : -1; }
+    if (mode == 0) return false;
+    return (CH == 8 && CW == 8) || (mode == 1 && CH == 7 && CW == 6);
 }
 
 template <int CH, int CW, bool WINO>
 static int launch_trunk2(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
     using G = TrunkGeom<CH, CW>;
-    constexpr int WPB = 8;  // one workgroup per CU: two waves per SIMD, two boards per wave
+    // one workgroup per CU, two boards per wave: two waves per SIMD -- or, for the Winograd conv2 of 8x8 planes, ONE wave per SIMD
+    // with 512 registers (all 16 frequency accumulators live) and the transformed weights in the LDS the other four waves would use
+    constexpr int WPB = (WINO && CH == 8 && CW == 8) ? 4 : 8;
     constexpr int lds_planes = 64 + WPB * 2 * G::WAVE_FLOATS * 4;
     constexpr int lds_bytes = lds_planes + ((WINO && lds_planes + 65536 <= 160 * 1024) ? 65536 : 0);  // + the Winograd U fragments where they fit
     static_assert(lds_bytes <= 160 * 1024, "k_trunk2 workgroup does not fit the CU's LDS");

@@ -415,10 +415,11 @@ orc_convnet *orc_convnet_create(int game, int H, int W) {
     n->game = game; n->H = H; n->W = W;
     if (game == ORC_OTHELLO) { n->ch = H; n->cw = W; n->A = H * W + 1; n->F1 = 1024; n->F2 = 512; }
     else { n->ch = W; n->cw = H; n->A = W; n->F1 = 64; n->F2 = 32; } /* connect4.py:360-365,399 */
-    {   /* the product's switch (use_wino in az_net.hip), followed here so that the two stay bit-equal: AZ_WINOGRAD=1 runs conv2 of
-           8x8 and 7x6 planes in the Winograd form (experimental, off by default) */
+    {   /* the product's policy (use_wino in az_net.hip), followed here so that the two stay bit-equal: conv2 in the Winograd form on
+           8x8 planes by default, on 7x6 planes with AZ_WINOGRAD=1, nowhere with AZ_WINOGRAD=0 */
         const char *e = getenv("AZ_WINOGRAD");
-        n->wino = (e && atoi(e) == 1) && ((n->ch == 8 && n->cw == 8) || (n->ch == 7 && n->cw == 6));
+        const int mode = e ? atoi(e) : -1;
+        n->wino = mode != 0 && ((n->ch == 8 && n->cw == 8) || (mode == 1 && n->ch == 7 && n->cw == 6));
     }
     n->FIN = NCH * (n->ch - 4) * (n->cw - 4);
     return n;

@@ -44,9 +44,10 @@ def test_baseline_players_and_argument_errors():
         MCT(eval_method=None, nn=object())
     fx = golden("stats.npz")
     assert abs(int(fx["ttt_rollout_draw"]) / int(fx["ttt_rollout_games"]) - 0.625) < 0.01
-    stats = Arena(GreedyPlayer(), RandomPlayer(), BOARDS_REGISTER["othello"](n=6)).play_games(40, return_stats=True)
-    assert len(stats["player1"]) > len(stats["player2"])  # report Table 3: greedy beats random
-    assert sum(stats["player1_starts"].values()) == 20 and sum(stats["player2_starts"].values()) == 20
+    np.random.seed(5)  # the reference's players draw from the global numpy state: pinned, so that the outcome is the same every run
+    stats = Arena(GreedyPlayer(), RandomPlayer(), BOARDS_REGISTER["othello"](n=6)).play_games(120, return_stats=True)
+    assert len(stats["player1"]) > len(stats["player2"])  # report Table 3: greedy beats random (60 : 35 over 10 K games)
+    assert sum(stats["player1_starts"].values()) == 60 and sum(stats["player2_starts"].values()) == 60
 
 
 @pytest.mark.parametrize("tag", ["tictactoe", "connect4", "othello6"])

@@ -259,10 +259,12 @@ def test_plane_shapes_without_a_trunk_kernel_are_refused():
     E.lib().az_net_destroy(h)
 
 
-def test_experimental_winograd_conv2_is_bit_equal_to_its_oracle_form():
-    """AZ_WINOGRAD=1 (read once per process by the library AND by the oracle): conv2 of 8x8 and 7x6 planes in the Winograd
-    F(2x2,3x3) form, in both trunk kernels.  Run in a child process: known answers within 1e-5 of the reference, network
-    bit-equal to the oracle's Winograd restatement at small and large batches, one self-play run sample for sample."""
+@pytest.mark.parametrize("mode,tags", [("1", "othello8 connect4"), ("0", "othello8")])
+def test_both_forms_of_conv2_are_bit_equal_to_their_oracle_forms(mode, tags):
+    """conv2 runs in the Winograd F(2x2,3x3) form on 8x8 planes by default (the rest of the suite); AZ_WINOGRAD (read once per
+    process by the library AND by the oracle) selects the other combinations: "1" adds the experimental 7x6 form, "0" runs
+    the direct form everywhere.  In a child process each: known answers within 1e-5 of the reference, the network bit-equal
+    to the oracle below 4096 boards (one board per wave) and above (two boards per wave), one self-play run sample for sample."""
     import os
     import subprocess
     import sys
@@ -275,10 +277,10 @@ from oracle import oracle as O
 from alphazero_amd import engine as E
 from test_gpu_net import nets
 from test_gpu_engine import sort_samples
-for tag in ('othello8', 'connect4'):
+for tag in %r.split():
     game, gid, H, W, A, n = TAGS[tag]
     fx, sd, onet, hnet = nets(tag)
-    assert onet.winograd()
+    assert onet.winograd() == (%r == '1')
     canon = fx['grids'].astype(np.float32) * fx['players'].astype(np.float32)[:, None, None]
     p, v = hnet.forward(torch.as_tensor(canon, device='cuda'))
     assert np.abs(p.cpu().numpy() - fx['probs']).max() < 1e-5 and np.abs(v.cpu().numpy() - fx['v']).max() < 1e-5
@@ -295,7 +297,7 @@ for tag in ('othello8', 'connect4'):
     got = sort_samples(eng.run(8))
     ref = O.selfplay(gid, H, W, 8, 20, ('conv', onet), seed=4)
     assert all(np.array_equal(got[k], ref[k]) for k in ('state', 'z', 'meta', 'visits', 'pi'))
-print('winograd ok')
-""" % (ROOT, ROOT)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AZ_WINOGRAD="1"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "winograd ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+print('conv2 forms ok')
+""" % (ROOT, ROOT, tags, mode)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AZ_WINOGRAD=mode), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "conv2 forms ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
