@@ -47,6 +47,16 @@ def stage_flops(CH, CW, F1, F2, A):
     return [conv, 2 * 32 * p4 * F1, 2 * F1 * F2, 2 * F2 * (A + 1)]
 
 
+def executed_conv_flops(CH, CW):
+    """FLOPs the trunk kernel EXECUTES per board on the matrix cores: conv2 of 8x8 planes runs in the Winograd F(2x2,3x3)
+    form (16 tiles x 16 frequencies x 32 x 32 MACs instead of 64 x 9 x 32 x 32; AZ_WINOGRAD=0 switches it off) -- the SURVEY's
+    algorithmic figure stays the numerator of `frac`, this one is reported beside it"""
+    p1, p3, p4 = CH * CW, (CH - 2) * (CW - 2), (CH - 4) * (CW - 4)
+    wino = (CH, CW) == (8, 8) and os.environ.get("AZ_WINOGRAD", "") != "0" or (CH, CW) == (7, 6) and os.environ.get("AZ_WINOGRAD", "") == "1"
+    conv2 = ((CH + 1) // 2) * ((CW + 1) // 2) * 16 * 32 * 32 if wino else p1 * 9 * 32 * 32
+    return 2 * (p1 * 9 * 32 + conv2 + p3 * 9 * 32 * 32 + p4 * 9 * 32 * 32), wino
+
+
 def algorithmic_bytes(CH, CW, F1, F2, A):
     """algorithmic HBM bytes per board of the four network stages (inputs + outputs; weights stay cache resident)"""
     fin = 32 * (CH - 4) * (CW - 4)
@@ -190,6 +200,11 @@ class Workload:
                 "achieved_uncorrected": fl[dom] * evals / (raw_ms[dom] * 1e-3) / 1e12,
                 "avg_boards_per_launch": evals / max(1, launches[dom]),
                 "algorithmic_flops_per_board": fl[dom], "boards_evaluated": evals,
+                **({"executed_flops_per_board": executed_conv_flops(*self.geom[:2])[0],
+                    "achieved_executed": executed_conv_flops(*self.geom[:2])[0] * evals / (tot_ms[0] * 1e-3) / 1e12,
+                    "frac_executed": executed_conv_flops(*self.geom[:2])[0] * evals / (tot_ms[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "conv2_form": "Winograd F(2x2,3x3): `frac` counts the SURVEY's algorithmic FLOPs of the direct form, `frac_executed` "
+                                  "the multiplications the kernel issues" if executed_conv_flops(*self.geom[:2])[1] else "direct"} if dom == 0 else {}),
                 "measured_on": "one separately profiled step after the timed region: HIP events on the engine's stream around every launch, "
                                "minus the calibrated cost of an empty event interval per launch",
                 "profiled_step_ms": 1e3 * dt,
