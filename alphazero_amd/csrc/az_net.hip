@@ -44,7 +44,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define PLANE_STRIDE(x) (((x) + 1) | 1)
 
 #ifdef AZ_PROBE  // diagnostic build only (make PROBE=1): per-phase shader-clock stamps of wave 0 of every block
-__device__ unsigned long long az_probe_buf[8192 * 8];
+__device__ unsigned long long az_probe_buf[8192 * 8];  // k_gemm: 8 words per block; k_trunk2: 8 words per (block, wave)
 #define STAMP(var) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define STAMP(var)
@@ -705,6 +705,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, WPB
     for (int i = lane; i < 2 * G::WAVE_FLOATS; i += 64) if (i % G::WAVE_FLOATS < G::INP) inp[i] = 0.0f;
     act[kk * OFF1 + m_lane * G::PS + G::P1] = 0.0f;  // every plane's spare slot: where conv2's out-of-plane taps read
     LDS_FENCE();
+#ifdef AZ_PROBE
+    unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tq5 = 0, ph_in = 0, ph_c1 = 0, ph_c2 = 0, ph_c3 = 0, ph_c4 = 0;
+    int n_pairs_done = 0;
+#endif
     while (true) {
         int nxt;
         NEXT_TICKET(nxt)
@@ -715,6 +719,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, WPB
         ln &= 63;  // gives the value range back (folds the tile bounds checks)
         const int b0 = 2 * pair;
         const bool two = b0 + 1 < B;
+        STAMP(tq0)
 #pragma unroll
         for (int u = 0; u < NIN; ++u) {
             const int q = ln + 64 * u;
@@ -726,6 +731,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, WPB
         auto to_lds = [&](int P_OUT) {
             return [=](int r, int oc, float v) { const int bd = r >= P_OUT ? 1 : 0; act[bd * OFF1 + oc * G::PS + (r - bd * P_OUT)] = v; };
         };
+        STAMP(tq1)
         {  // conv1 1->32, pad 1, as a K = 10 product: taps 0..8, tap 9 carries zero weights
             f32x16 acc[MT1];
             int pbase[MT1];
@@ -757,6 +763,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, WPB
                 }
         }
         LDS_FENCE();
+        STAMP(tq2)
         if constexpr (WINO) {  // conv2 32->32, pad 1, Winograd form: one board after the other (a board's tiles fill a 16-row MFMA tile)
             if constexpr (ULDS && WPB == 4) {
                 conv2_wino32<CH, CW, G::PS, OFF1>(act, u_lds, tp.cb[0], ln);
@@ -779,6 +786,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, WPB
             conv_epilogue<G::P1>(ln, acc, acc16, to_lds(G::P1));
         }
         LDS_FENCE();
+        STAMP(tq3)
         {  // conv3 32->32, valid
             f32x16 acc[PL3::MTA];
             f32x4 acc16[2];
@@ -789,6 +797,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, WPB
             conv_epilogue<G::P3>(ln, acc, acc16, to_lds(G::P3));
         }
         LDS_FENCE();
+        STAMP(tq4)
         {  // conv4 32->32, valid -> flattened NCHW features
             f32x16 acc[PL4::MTA];
             f32x4 acc16[2];
@@ -818,9 +827,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, WPB
                 });
             }
         }
+#ifdef AZ_PROBE
+        STAMP(tq5)
+        ph_in += tq1 - tq0; ph_c1 += tq2 - tq1; ph_c2 += tq3 - tq2; ph_c3 += tq4 - tq3; ph_c4 += tq5 - tq4; ++n_pairs_done;
+#endif
         pair = nxt;
         if (pair >= pairs) break;
     }
+#ifdef AZ_PROBE
+    if (lane == 0 && blockIdx.x < 1024) {  // az_probe_buf: 8 words per (block, wave)
+        unsigned long long *o = az_probe_buf + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = ph_in; o[1] = ph_c1; o[2] = ph_c2; o[3] = ph_c3; o[4] = ph_c4; o[5] = (unsigned long long)n_pairs_done; o[6] = tq5; o[7] = 0;
+    }
+#endif
 #undef NEXT_TICKET
 #undef LOAD_INPUT
 #undef LOAD_W0
