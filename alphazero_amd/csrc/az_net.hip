@@ -35,6 +35,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 #define NCH 32
@@ -316,13 +317,21 @@ AZ_D void conv2_wino32(float *act, const float4 *u4, const float *__restrict__ b
     for (int f = 0; f < 16; ++f) ub[f] = ul[f * 64];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        float T[4][4], V[16];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { T[0][b] = d[b] - d[8 + b]; T[1][b] = d[4 + b] + d[8 + b]; T[2][b] = d[8 + b] - d[4 + b]; T[3][b] = d[4 + b] - d[12 + b]; }
+        // the same 32 IEEE additions, two per instruction where the pairing allows (v_pk_add_f32): rows over column pairs,
+        // then (V[i][0], V[i][3]) = (T[i][0], T[i][1]) - (T[i][2], T[i][3]) in one packed subtraction
+        float V[16];
+        f32x2 Tl[4], Th[4];  // T[i][0..1], T[i][2..3]
+        {
+            const f32x2 d0l = {d[0], d[1]}, d0h = {d[2], d[3]}, d1l = {d[4], d[5]}, d1h = {d[6], d[7]};
+            const f32x2 d2l = {d[8], d[9]}, d2h = {d[10], d[11]}, d3l = {d[12], d[13]}, d3h = {d[14], d[15]};
+            Tl[0] = d0l - d2l; Th[0] = d0h - d2h; Tl[1] = d1l + d2l; Th[1] = d1h + d2h;
+            Tl[2] = d2l - d1l; Th[2] = d2h - d1h; Tl[3] = d1l - d3l; Th[3] = d1h - d3h;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            V[4 * i + 0] = T[i][0] - T[i][2]; V[4 * i + 1] = T[i][1] + T[i][2];
-            V[4 * i + 2] = T[i][2] - T[i][1]; V[4 * i + 3] = T[i][1] - T[i][3];
+            const f32x2 v03 = Tl[i] - Th[i];
+            V[4 * i + 0] = v03.x; V[4 * i + 3] = v03.y;
+            V[4 * i + 1] = Tl[i].y + Th[i].x; V[4 * i + 2] = Th[i].x - Tl[i].y;
         }
         if (j + 1 < 16) {
 #pragma unroll
@@ -350,22 +359,30 @@ AZ_D void conv2_wino32(float *act, const float4 *u4, const float *__restrict__ b
     }
     LDS_FENCE();  // every read of the input planes has returned: the output may overwrite them
     const float bv = bias[m];
+    const f32x2 bv2 = {bv, bv};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = 8 * (i / 4) + 4 * kk + (i % 4);  // C layout of 32x32x2: this register's row (tile), column lane & 31
-        const int rb = r / NTL, rt = r % NTL, y0 = 2 * (rt / TW), x0 = 2 * (rt % TW);
-        float R[4][2];
+    for (int ip = 0; ip < 8; ++ip) {  // two accumulator registers (two neighbouring tiles) per step: packed f32 additions
+        f32x2 R[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            R[q][0] = (acc[4 * q + 0][i] + acc[4 * q + 1][i]) + acc[4 * q + 2][i];
-            R[q][1] = (acc[4 * q + 1][i] - acc[4 * q + 2][i]) - acc[4 * q + 3][i];
+            const f32x2 a0 = {acc[4 * q + 0][2 * ip], acc[4 * q + 0][2 * ip + 1]}, a1 = {acc[4 * q + 1][2 * ip], acc[4 * q + 1][2 * ip + 1]};
+            const f32x2 a2 = {acc[4 * q + 2][2 * ip], acc[4 * q + 2][2 * ip + 1]}, a3 = {acc[4 * q + 3][2 * ip], acc[4 * q + 3][2 * ip + 1]};
+            R[q][0] = (a0 + a1) + a2;
+            R[q][1] = (a1 - a2) - a3;
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float y0v = ((R[0][c] + R[1][c]) + R[2][c]) + bv, y1v = ((R[1][c] - R[2][c]) - R[3][c]) + bv;
-            if (r < 2 * NTL && x0 + c < CW) {
-                if (y0 < CH) act[rb * OFF1 + m * PS + y0 * CW + x0 + c] = y0v > 0.0f ? y0v : 0.0f;
-                if (y0 + 1 < CH) act[rb * OFF1 + m * PS + (y0 + 1) * CW + x0 + c] = y1v > 0.0f ? y1v : 0.0f;
+            const f32x2 y0v = ((R[0][c] + R[1][c]) + R[2][c]) + bv2, y1v = ((R[1][c] - R[2][c]) - R[3][c]) + bv2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * ip + h;
+                const int r = 8 * (i / 4) + 4 * kk + (i % 4);  // C layout of 32x32x2: this register's row (tile), column lane & 31
+                const int rb = r / NTL, rt = r % NTL, y0 = 2 * (rt / TW), x0 = 2 * (rt % TW);
+                const float u0 = h ? y0v.y : y0v.x, u1 = h ? y1v.y : y1v.x;
+                if (r < 2 * NTL && x0 + c < CW) {
+                    if (y0 < CH) act[rb * OFF1 + m * PS + y0 * CW + x0 + c] = u0 > 0.0f ? u0 : 0.0f;
+                    if (y0 + 1 < CH) act[rb * OFF1 + m * PS + (y0 + 1) * CW + x0 + c] = u1 > 0.0f ? u1 : 0.0f;
+                }
             }
         }
     }
