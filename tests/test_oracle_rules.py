@@ -84,3 +84,22 @@ def test_start_position_moves():
     # start-position legal moves (2,4), (3,5), (4,2), (5,3)
     b = O.new_board(O.OTHELLO, 8, 8)
     assert O.legal_moves(b) == [2 * 8 + 4, 3 * 8 + 5, 4 * 8 + 2, 5 * 8 + 3]
+
+
+def test_random_playout_envelope_matches_the_reference_measurements():
+    """SURVEY Appendix C (measured on the reference with 60 random Othello 8x8 playouts): 60.6 plies per game (60-63),
+    0.94 % forced passes, mean branching factor 8.34 (max 22).  The oracle's rules over 300 random playouts must sit in
+    the same envelope (statistical: seeds fixed, bounds wide enough for the sample sizes on both sides)."""
+    n_games = 300
+    grids, players, actions = O.random_positions(O.OTHELLO, 8, 8, 2024, n_games, 30000)
+    start = O.new_board(O.OTHELLO, 8, 8).grid_np().reshape(-1)
+    is_start = (grids == start).all(1) & (players == 1)
+    assert is_start.sum() == n_games                       # every game was recorded from its first position to its last move
+    plies = np.diff(np.append(np.flatnonzero(is_start), len(players)))
+    assert 60.0 <= plies.mean() <= 61.5 and plies.min() >= 50 and plies.max() <= 68, (plies.mean(), plies.min(), plies.max())  # a few games end with empty cells
+    passes = (actions == 64)
+    assert 0.002 < passes.mean() < 0.02, passes.mean()
+    legal = O.batch_legal(O.OTHELLO, 8, 8, grids, players)[:, :64].sum(1)
+    assert (legal[passes] == 0).all() and (legal[~passes] > 0).all()
+    branching = legal[~passes]
+    assert 7.8 < branching.mean() < 8.9 and branching.max() <= 33, (branching.mean(), branching.max())
