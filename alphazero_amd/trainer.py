@@ -329,6 +329,8 @@ class AlphaZeroTrainer:
             # all evaluation games at once on the GPU(s) (same stats dict as Arena.play_games)
             from .arena import BatchedArena
             if c.eval_opponent == "previous":
+                if self.prev_nn is None:
+                    raise ValueError("eval_opponent = 'previous' needs update_network() to have run: there is no previous network yet")
                 opp_arg, p2_name = self.prev_nn, "AlphaZeroPlayer(previous network)"
             else:
                 opp_arg = c.eval_opponent
