@@ -1048,6 +1048,187 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const float *__restrict__ A, co
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gemm_solo: the same product for LARGE row counts (from one 256x256 tile per CU up) with ONE wave per SIMD: every wave
+// owns a 128x128 tile (16 accumulator tiles of 32x32 = 256 registers of its 512), the workgroup a 256x256 tile.  Against
+// k_gemm's 64x64 per wave this halves the LDS fragment reads and the barriers per MFMA (16 MFMAs per 8 fragment reads, one
+// barrier per 256 MFMAs per wave) -- the two-waves-per-SIMD kernel spends 46 % of each wave's time outside its MFMA chains
+// (in-kernel stamps) and leaves the pipe idle whenever both partners are there (MFMA busy 76-80 %).  A K tile of a wave is
+// 16 k-steps x 16 MFMAs = 16 K cycles of matrix work, several times the global-memory latency: the next tile's loads are
+// issued at the top of the tile and stored to the other LDS buffer at its end, one register set, a runtime K loop.
+// Accumulation: bias, then k ascending on v_mfma_f32_32x32x2_f32 -- the chain of k_gemm / k_dense_small / the oracle.
+// ---------------------------------------------------------------------------------------------
+template <bool RELU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gemm_solo(const float *__restrict__ A, const float *__restrict__ Bw,
+                                                                                           const float *__restrict__ bias, float *__restrict__ C, int M, int N,
+                                                                                           int K, const int *__restrict__ dyn_count) {
+    if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
+    constexpr int BM = 256, BN = 256, BK = 32, ASTR = BK + 1, BSTR = BN;
+    const int nbx = N / BN, nb = nbx * (int)gridDim.y;
+    int bid = (int)blockIdx.y * nbx + (int)blockIdx.x;
+    if (nb % 8 == 0) bid = (bid % 8) * (nb / 8) + bid / 8;  // XCD-aware tile order, as k_gemm
+    const int tile_y = bid / nbx, tile_x = bid % nbx;
+    if (tile_y * BM >= M) return;
+#ifdef AZ_PROBE
+    unsigned long long pk0, pk1, pl0, pl1;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    STAMP(pk0)
+#endif
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float *As = gsm;                  // [2][BM][ASTR]
+    float *Bs = gsm + 2 * BM * ASTR;  // [2][BK][BSTR]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 128;
+    const int bm0 = tile_y * BM, bn0 = tile_x * BN;
+    // accumulators start at the bias THROUGH the matrix pipe (1 * bias[col] + 0 * 0 on a zero accumulator: exact): a plain splat of
+    // four bias values over 256 registers makes the compiler hold a second copy of them and spill (measured: 100 dwords)
+    f32x16 acc[4][4];
+    {
+        const float one = lane < 32 ? 1.0f : 0.0f;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const float bv = lane < 32 ? bias[bn0 + wn0 + tn * 32 + lane] : 0.0f;
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                acc[tm][tn] = MFMA32(one, bv, z);
+            }
+        }
+    }
+    // staging slots: A float4 #i of this thread is (row (tid >> 3) + 32 i, q = tid & 7), BK / 4 = 8 per row; B float4 #i is
+    // (k row (tid >> 6) + 4 i, c4 = tid & 63), BN / 4 = 64 per row.  Named registers, not arrays: arrays behind lambdas stayed in scratch.
+    // Addresses are a wave-uniform base (A + k0, B + (k0 + 4 i) N: scalar registers) plus a 32-bit per-lane byte offset fixed for the
+    // whole kernel -- no vector address arithmetic per tile, so a load can sit between two MFMAs without holding the next one up.
+    const int arow = tid >> 3, aq = tid & 7;
+    unsigned aoff0, aoff1, aoff2, aoff3, aoff4, aoff5, aoff6, aoff7;
+#define SOLO_AOFF(i)                                                       \
+    {                                                                      \
+        int gr = bm0 + arow + 32 * i;                                      \
+        gr = gr < M ? gr : M - 1;                                          \
+        aoff##i = (unsigned)(((size_t)gr * K + 4 * aq) * sizeof(float));   \
+    }
+    SOLO_AOFF(0) SOLO_AOFF(1) SOLO_AOFF(2) SOLO_AOFF(3) SOLO_AOFF(4) SOLO_AOFF(5) SOLO_AOFF(6) SOLO_AOFF(7)
+    const unsigned boff = (unsigned)(((size_t)(tid >> 6) * N + 4 * (tid & 63)) * sizeof(float));
+    const float *Bt = Bw + bn0;
+    float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+#define SOLO_LDA(i, k0) ra##i = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(A + (k0)) + aoff##i);
+#define SOLO_LDB(i, k0) rb##i = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Bt + (size_t)((k0) + 4 * i) * N) + boff);
+#define SOLO_LD(i, k0) { SOLO_LDA(i, k0) SOLO_LDB(i, k0) }
+#define SOLO_ISSUE(k0) SOLO_LD(0, k0) SOLO_LD(1, k0) SOLO_LD(2, k0) SOLO_LD(3, k0) SOLO_LD(4, k0) SOLO_LD(5, k0) SOLO_LD(6, k0) SOLO_LD(7, k0)
+#define SOLO_STA(i, as_)                       \
+    {                                          \
+        float *d = (as_) + 32 * i * ASTR;      \
+        d[0] = ra##i.x;                        \
+        d[1] = ra##i.y;                        \
+        d[2] = ra##i.z;                        \
+        d[3] = ra##i.w;                        \
+    }
+#define SOLO_STB(i, bs_) *reinterpret_cast<float4 *>((bs_) + 4 * i * BSTR) = rb##i;
+#define SOLO_ST(i) { SOLO_STA(i, as_) SOLO_STB(i, bs_) }
+#define SOLO_STASH(buf)                                                                                                      \
+    {                                                                                                                        \
+        float *as_ = As + (buf) * BM * ASTR + arow * ASTR + 4 * aq, *bs_ = Bs + (buf) * BK * BSTR + (tid >> 6) * BSTR + 4 * (tid & 63); \
+        SOLO_ST(0) SOLO_ST(1) SOLO_ST(2) SOLO_ST(3) SOLO_ST(4) SOLO_ST(5) SOLO_ST(6) SOLO_ST(7)                              \
+    }
+    // one K tile of the wave: 16 k-steps of 16 MFMAs; the fragments of step ks + 1 are read under the MFMAs of step ks.  With NEXT
+    // the following tile is staged under the same MFMAs: its global loads go out two per k-step over steps 0-7, the registers go to the
+    // other LDS buffer one slot per k-step over steps 8-15.  One wave per SIMD means nothing else covers an instruction that is not
+    // in the shadow of an MFMA (64 cycles each), so the memory instructions are dealt out by hand: at most two LDS reads and one
+    // staging instruction in front of every group of four MFMAs, fenced so that the scheduler does not gather them again.
+    // scheduling fence that instruction selection honours too: a plain sched_barrier left the LDS reads free to gather ahead of it
+#define SOLO_FENCE() { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define SOLO_COMPUTE(buf, NEXT, k0n)                                                                             \
+    {                                                                                                            \
+        const float *as = As + (buf) * BM * ASTR + (wm0 + (lane & 31)) * ASTR + (lane >> 5);                     \
+        const float *bs = Bs + (buf) * BK * BSTR + (lane >> 5) * BSTR + wn0 + (lane & 31);                       \
+        float *as_ = As + ((buf) ^ 1) * BM * ASTR + arow * ASTR + 4 * aq, *bs_ = Bs + ((buf) ^ 1) * BK * BSTR + (tid >> 6) * BSTR + 4 * (tid & 63); \
+        float afr[2][4], bfr[2][4];                                                                              \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) { afr[0][x] = as[x * 32 * ASTR]; bfr[0][x] = bs[x * 32]; } \
+        _Pragma("unroll") for (int ks = 0; ks < BK / 2; ++ks) {                                                  \
+            _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) {                                                   \
+                /* quarter tm of the k-step: two fragment reads of step ks + 1 and one staging instruction, then 4 MFMAs */ \
+                if (ks + 1 < BK / 2) {                                                                           \
+                    afr[(ks + 1) & 1][tm] = as[tm * 32 * ASTR + (ks + 1) * 2];                                   \
+                    bfr[(ks + 1) & 1][tm] = bs[(ks + 1) * 2 * BSTR + tm * 32];                                   \
+                }                                                                                                \
+                if (NEXT && tm == 0) {                                                                           \
+                    if (ks == 0) SOLO_LDA(0, k0n)                                                                \
+                    if (ks == 1) SOLO_LDA(1, k0n)                                                                \
+                    if (ks == 2) SOLO_LDA(2, k0n)                                                                \
+                    if (ks == 3) SOLO_LDA(3, k0n)                                                                \
+                    if (ks == 4) SOLO_LDA(4, k0n)                                                                \
+                    if (ks == 5) SOLO_LDA(5, k0n)                                                                \
+                    if (ks == 6) SOLO_LDA(6, k0n)                                                                \
+                    if (ks == 7) SOLO_LDA(7, k0n)                                                                \
+                    if (ks == 8) SOLO_STA(0, as_)                                                                \
+                    if (ks == 9) SOLO_STA(1, as_)                                                                \
+                    if (ks == 10) SOLO_STA(2, as_)                                                               \
+                    if (ks == 11) SOLO_STA(3, as_)                                                               \
+                    if (ks == 12) SOLO_STA(4, as_)                                                               \
+                    if (ks == 13) SOLO_STA(5, as_)                                                               \
+                    if (ks == 14) SOLO_STA(6, as_)                                                               \
+                    if (ks == 15) SOLO_STA(7, as_)                                                               \
+                }                                                                                                \
+                if (NEXT && tm == 2) {                                                                           \
+                    if (ks == 0) SOLO_LDB(0, k0n)                                                                \
+                    if (ks == 1) SOLO_LDB(1, k0n)                                                                \
+                    if (ks == 2) SOLO_LDB(2, k0n)                                                                \
+                    if (ks == 3) SOLO_LDB(3, k0n)                                                                \
+                    if (ks == 4) SOLO_LDB(4, k0n)                                                                \
+                    if (ks == 5) SOLO_LDB(5, k0n)                                                                \
+                    if (ks == 6) SOLO_LDB(6, k0n)                                                                \
+                    if (ks == 7) SOLO_LDB(7, k0n)                                                                \
+                    if (ks == 8) SOLO_STB(0, bs_)                                                                \
+                    if (ks == 9) SOLO_STB(1, bs_)                                                                \
+                    if (ks == 10) SOLO_STB(2, bs_)                                                               \
+                    if (ks == 11) SOLO_STB(3, bs_)                                                               \
+                    if (ks == 12) SOLO_STB(4, bs_)                                                               \
+                    if (ks == 13) SOLO_STB(5, bs_)                                                               \
+                    if (ks == 14) SOLO_STB(6, bs_)                                                               \
+                    if (ks == 15) SOLO_STB(7, bs_)                                                               \
+                }                                                                                                \
+                SOLO_FENCE()                                                                                     \
+                _Pragma("unroll") for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = MFMA32(afr[ks & 1][tm], bfr[ks & 1][tn], acc[tm][tn]); \
+                SOLO_FENCE()                                                                                     \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+    const int T = K / BK;
+    SOLO_ISSUE(0)
+    SOLO_STASH(0)
+    __syncthreads();
+    STAMP(pl0)
+    for (int t = 0; t + 1 < T; ++t) {  // the last tile is peeled: no conditional staging inside the loop
+        SOLO_COMPUTE(t & 1, true, (t + 1) * BK)
+        __syncthreads();
+    }
+    STAMP(pl1)
+    SOLO_COMPUTE((T - 1) & 1, false, 0)
+    // C/D layout of 32x32x2: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = bn0 + wn0 + tn * 32 + (lane & 31);
+                float v = acc[tm][tn][r];
+                if (RELU) v = v > 0.0f ? v : 0.0f;
+                if (row < M) C[(size_t)row * N + col] = v;
+            }
+#ifdef AZ_PROBE
+    STAMP(pk1)
+    if (tid == 0) {  // shader-clock cycles of the whole block and of its main loop, the 100 MHz real-time clock over the same span
+        unsigned long long *pb = az_probe_buf + (size_t)((int)blockIdx.y * nbx + (int)blockIdx.x) % 8192 * 8;
+        pb[0] = pk1 - pk0; pb[1] = pl1 - pl0; pb[2] = __builtin_amdgcn_s_memrealtime() - rt0; pb[3] = (unsigned long long)(T - 1);
+    }
+#endif
+}
+
+
 // Dense layer for a handful of rows (single-game search, small arenas): one wavefront per (row, 64 output columns),
 // plain fmaf in k order -- the same chain the MFMA tiles compute, so the results are bit-identical -- with 16 to 32 weight
 // loads in flight per lane.  The tiled GEMM walks its K tiles serially inside one workgroup (~1 us per tile whatever the
@@ -2132,6 +2313,24 @@ static int launch_gemm(const float *A, const float *Bw, const float *bias, float
         if (relu) hipLaunchKernelGGL((k_dense_small<true>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
         else hipLaunchKernelGGL((k_dense_small<false>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
         return AZ_OK;
+    }
+    {   // large row counts: the one-wave-per-SIMD kernel (256x256 workgroup tiles), from one tile per CU up.  AZ_GEMM_SOLO=0 / 1 forces.
+        static int solo = -2;
+        if (solo == -2) { const char *e = getenv("AZ_GEMM_SOLO"); solo = e ? atoi(e) : -1; }
+        const long long tiles = (long long)((M + 255) / 256) * (N / 256);
+        if (solo != 0 && N % 256 == 0 && (solo == 1 || tiles >= 256)) {
+            constexpr int lds = 4 * (2 * 256 * 33 + 2 * 32 * 256);
+            static bool attr_set = false;
+            if (!attr_set) {
+                AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_solo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_solo<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                attr_set = true;
+            }
+            dim3 grid(N / 256, (M + 255) / 256);
+            if (relu) hipLaunchKernelGGL((k_gemm_solo<true>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+            else hipLaunchKernelGGL((k_gemm_solo<false>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+            return AZ_OK;
+        }
     }
     // pick the largest tile that still gives every CU two resident blocks (512 blocks on 256 CUs):
     // a block's barrier and LDS-fill phases then overlap the other block's MFMAs

@@ -74,10 +74,11 @@ def test_large_batch_kernel_equals_small_batch_kernel(tag):
     """from 4096 boards up the trunk runs two boards per wave on 32x32x2 MFMA (k_trunk2), below that one board per
     wave on 16x16x4: same accumulation order, so the same boards must give the same bits in either -- odd and ragged
     batch sizes included (the small-batch results are the ones checked against the oracle above).  The dense layers
-    switch tile shapes with the batch as well (128x128 from 8192 / 16384 rows)."""
+    switch tile shapes with the batch as well (128x128 from 8192 / 16384 rows; the one-wave-per-SIMD k_gemm_solo with 256x256
+    workgroup tiles from one tile per CU up: 16384 rows for fc1, 32768 for fc2)."""
     game, gid, H, W, A, n = TAGS[tag]
     fx, sd, onet, _ = nets(tag)
-    sizes = (4096, 4099, 6001, 9000) + ((16500,) if tag == "othello8" else ())  # 16500: both dense layers on the 128x128 GEMM tile
+    sizes = (4096, 4099, 6001, 9000) + ((16500, 33000) if tag == "othello8" else ())  # 16500: fc1 on k_gemm_solo, fc2 on the 128x128 tile; 33000: both solo
     hnet = E.HipNet(gid, H, W, sd, max_batch=max(sizes))
     grids, players, _ = O.random_positions(gid, H, W, 11, 40, 1200)
     canon = torch.as_tensor((grids * players[:, None]).astype(np.float32), device="cuda")
