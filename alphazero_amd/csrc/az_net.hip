@@ -287,9 +287,13 @@ AZ_D void conv2_wino(float *act, const float4 *wu4, const float *__restrict__ bi
 // 16-row form) and comes from LDS.  All 16 frequency accumulators are live at once (256 registers): this form runs in the
 // one-wave-per-SIMD variant of k_trunk2 (4 waves per workgroup, 512 registers per wave).  Same chains (ic ascending per
 // frequency, from 0), same transforms, same operation order as conv2_wino and the oracle: identical bits.
-//   u4: [jq (4)][f (16)][lane (64)] float4 = k-steps 4 jq .. 4 jq + 3 of frequency f: U[f][ic = 2 j + (lane >> 5)][oc = lane & 31]
+//   u2: [jp (8)][f (16)][lane (64)] float2 = k-steps 2 jp, 2 jp + 1 of frequency f: U[f][ic = 2 j + (lane >> 5)][oc = lane & 31]
+// Software pipeline, two k-steps deep: while the 16 MFMAs of k-step j run on V(j), the VALU transforms the patch of k-step j + 1
+// (read from LDS during k-step j - 1) into V(j + 1) and the LDS reads of the patch of k-step j + 2 go out.  With one wave per SIMD
+// a transform that sits between its own LDS reads and its own MFMAs stops the matrix pipe for an LDS latency twice per k-step
+// (measured: conv2 at 61 % MFMA occupancy in that form).
 template <int CH, int CW, int PS, int OFF1>
-AZ_D void conv2_wino32(float *act, const float4 *u4, const float *__restrict__ bias, int lane) {
+AZ_D void conv2_wino32(float *act, const float2 *u2, const float *__restrict__ bias, int lane) {
     constexpr int TW = (CW + 1) / 2, NTL = ((CH + 1) / 2) * TW, P1 = CH * CW;
     static_assert(2 * NTL <= 32 && PS > P1, "the tiles of two boards fill one 32-row MFMA tile");
     const int m = lane & 31, kk = lane >> 5;
@@ -308,55 +312,78 @@ AZ_D void conv2_wino32(float *act, const float4 *u4, const float *__restrict__ b
     for (int f = 0; f < 16; ++f)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[f][i] = 0.0f;
-    const float4 *ul = u4 + lane;
-    float d[16];
+    const float2 *ul = u2 + lane;
+    float d[16], V[2][16];
+    // the same 32 IEEE additions as conv2_wino, two per instruction where the pairing allows (v_pk_add_f32): rows over column pairs
+    // (stage 1: T = B^T d, eight packed operations), then per row i (stage 2, three operations) (V[i][0], V[i][3]) = (T[i][0], T[i][1]) -
+    // (T[i][2], T[i][3]) in one packed subtraction, V[i][1] = T[i][1] + T[i][2], V[i][2] = T[i][2] - T[i][1]
+#define DP(e) ((f32x2){d[e], d[(e) + 1]})
+#define WINO32_STAGE1(q, Tl, Th)                              \
+    {                                                         \
+        if ((q) == 0) Tl[0] = DP(0) - DP(8);                  \
+        if ((q) == 1) Th[0] = DP(2) - DP(10);                 \
+        if ((q) == 2) Tl[1] = DP(4) + DP(8);                  \
+        if ((q) == 3) Th[1] = DP(6) + DP(10);                 \
+        if ((q) == 4) Tl[2] = DP(8) - DP(4);                  \
+        if ((q) == 5) Th[2] = DP(10) - DP(6);                 \
+        if ((q) == 6) Tl[3] = DP(4) - DP(12);                 \
+        if ((q) == 7) Th[3] = DP(6) - DP(14);                 \
+    }
+#define WINO32_STAGE2(i, c, Tl, Th, Vout)                                                          \
+    {                                                                                              \
+        if ((c) == 0) { const f32x2 v03 = Tl[i] - Th[i]; Vout[4 * (i) + 0] = v03.x; Vout[4 * (i) + 3] = v03.y; } \
+        if ((c) == 1) Vout[4 * (i) + 1] = Tl[i].y + Th[i].x;                                       \
+        if ((c) == 2) Vout[4 * (i) + 2] = Th[i].x - Tl[i].y;                                       \
+    }
+    // fence that instruction selection honours as well as the scheduler (a bare sched_barrier lets LDS reads gather in front of it)
+#define WINO32_FENCE() { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int e = 0; e < 16; ++e) d[e] = act[off[e]];
-    float4 ub[16];
+    float2 ub[2][16];  // U fragments of k-steps (2 jp, 2 jp + 1), double-buffered
 #pragma unroll
-    for (int f = 0; f < 16; ++f) ub[f] = ul[f * 64];
+    for (int f = 0; f < 16; ++f) ub[0][f] = ul[f * 64];
+    {
+        f32x2 Tl[4], Th[4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) WINO32_STAGE1(q, Tl, Th)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) WINO32_STAGE2(i, c, Tl, Th, V[0])
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d[e] = act[off[e] + 2 * PS];
+    WINO32_FENCE()
+    // one wave per SIMD: nothing else fills the matrix pipe, so everything that is not an MFMA is dealt out by hand into the 64-cycle
+    // shadows of this k-step's 16 MFMAs.  Slot g, in front of MFMA g: stage-1 operation g (g < 8), one stage-2 operation (slots 2-13),
+    // two LDS reads of the patch of k-step j + 2 (slots 8-15, once stage 1 has consumed d; rows in the order the next stage 1 wants
+    // them) and, on even k-steps, the U fragment pair of frequency g for k-steps j + 2, j + 3.
+    constexpr int DORD[16] = {0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15};
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        // the same 32 IEEE additions, two per instruction where the pairing allows (v_pk_add_f32): rows over column pairs,
-        // then (V[i][0], V[i][3]) = (T[i][0], T[i][1]) - (T[i][2], T[i][3]) in one packed subtraction
-        float V[16];
-        f32x2 Tl[4], Th[4];  // T[i][0..1], T[i][2..3]
-        {
-            const f32x2 d0l = {d[0], d[1]}, d0h = {d[2], d[3]}, d1l = {d[4], d[5]}, d1h = {d[6], d[7]};
-            const f32x2 d2l = {d[8], d[9]}, d2h = {d[10], d[11]}, d3l = {d[12], d[13]}, d3h = {d[14], d[15]};
-            Tl[0] = d0l - d2l; Th[0] = d0h - d2h; Tl[1] = d1l + d2l; Th[1] = d1h + d2h;
-            Tl[2] = d2l - d1l; Th[2] = d2h - d1h; Tl[3] = d1l - d3l; Th[3] = d1h - d3h;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x2 v03 = Tl[i] - Th[i];
-            V[4 * i + 0] = v03.x; V[4 * i + 3] = v03.y;
-            V[4 * i + 1] = Tl[i].y + Th[i].x; V[4 * i + 2] = Th[i].x - Tl[i].y;
-        }
-        if (j + 1 < 16) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) d[e] = act[off[e] + 2 * (j + 1) * PS];
-        }
-        float bcur[16];
-#pragma unroll
-        for (int f = 0; f < 16; ++f) bcur[f] = (j % 4 == 0) ? ub[f].x : ((j % 4 == 1) ? ub[f].y : ((j % 4 == 2) ? ub[f].z : ub[f].w));
-        if (j % 4 == 3 && j + 1 < 16) {
-#pragma unroll
-            for (int f = 0; f < 16; ++f) ub[f] = ul[((j + 1) / 4 * 16 + f) * 64];
-        }
-#pragma unroll
-        for (int f = 0; f < 16; ++f) acc[f] = MFMA32(V[f], bcur[f], acc[f]);
-#pragma unroll
-        for (int f = 0; f < 16; ++f) asm volatile("" : "+a"(acc[f]));
-        // one wave per SIMD: nothing else fills the matrix pipe, so the next k-step's LDS reads and transform are spread
-        // between this k-step's MFMAs (1 MFMA, 2 VALU, 2 LDS reads, 16 times)
+        f32x2 Tl[4], Th[4];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (j + 1 < 16) {
+                if (g < 8) WINO32_STAGE1(g, Tl, Th)
+                if (g >= 2 && g < 14) WINO32_STAGE2((g - 2) / 3, (g - 2) % 3, Tl, Th, V[(j + 1) & 1])
+            }
+            if (j + 2 < 16 && g >= 8) {
+                const int e0 = DORD[2 * (g - 8)], e1 = DORD[2 * (g - 8) + 1];
+                d[e0] = act[off[e0] + 2 * (j + 2) * PS];
+                d[e1] = act[off[e1] + 2 * (j + 2) * PS];
+            }
+            if (j % 2 == 0 && j + 2 < 16) ub[(j / 2 + 1) & 1][g] = ul[((j / 2 + 1) * 16 + g) * 64];
+            WINO32_FENCE()
+            acc[g] = MFMA32(V[j & 1][g], (j % 2 == 0) ? ub[(j / 2) & 1][g].x : ub[(j / 2) & 1][g].y, acc[g]);
+            asm volatile("" : "+a"(acc[g]));
+            WINO32_FENCE()
         }
     }
+#undef WINO32_STAGE1
+#undef WINO32_STAGE2
+#undef WINO32_FENCE
+#undef DP
     LDS_FENCE();  // every read of the input planes has returned: the output may overwrite them
     const float bv = bias[m];
     const f32x2 bv2 = {bv, bv};
@@ -668,7 +695,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, WPB
     if constexpr (ULDS) {
         static_assert((16 + WPB * 2 * G::WAVE_FLOATS) % 4 == 0, "16-byte alignment of the U region");
         const float4 *src = reinterpret_cast<const float4 *>(WPB == 4 ? tp.wu32 : tp.wu);  // one wave per SIMD: the 32-row form
-        for (int i = threadIdx.x; i < 4096; i += 64 * WPB) u_lds[i] = src[i];
+        if constexpr (WPB == 4) {  // conv2_wino32 reads two k-steps at a time: [jp (8)][f (16)][lane (64)] float2, conflict-free 8-byte reads
+            float2 *u2 = reinterpret_cast<float2 *>(u_lds);
+            for (int i = threadIdx.x; i < 4096; i += 64 * WPB) {
+                const float4 v = src[i];
+                const int jq = i >> 10, fl = i & 1023;  // source: [jq (4)][f][lane] float4 = k-steps 4 jq .. 4 jq + 3
+                u2[(2 * jq) * 1024 + fl] = make_float2(v.x, v.y);
+                u2[(2 * jq + 1) * 1024 + fl] = make_float2(v.z, v.w);
+            }
+        } else {
+            for (int i = threadIdx.x; i < 4096; i += 64 * WPB) u_lds[i] = src[i];
+        }
     }
     __syncthreads();  // the only workgroup barrier: the waves are independent from here on
     const int simd = (__builtin_amdgcn_s_getreg((4 << 11) | (4 << 6) | 4) & 3);  // HW_REG_HW_ID bits [5:4]
@@ -783,7 +820,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, WPB
         STAMP(tq2)
         if constexpr (WINO) {  // conv2 32->32, pad 1, Winograd form: one board after the other (a board's tiles fill a 16-row MFMA tile)
             if constexpr (ULDS && WPB == 4) {
-                conv2_wino32<CH, CW, G::PS, OFF1>(act, u_lds, tp.cb[0], ln);
+                conv2_wino32<CH, CW, G::PS, OFF1>(act, reinterpret_cast<const float2 *>(u_lds), tp.cb[0], ln);
             } else if constexpr (ULDS) {
                 conv2_wino<CH, CW, G::PS, 2>(act, u_lds, tp.cb[0], ln);
                 conv2_wino<CH, CW, G::PS, 2>(act + OFF1, u_lds, tp.cb[0], ln);
