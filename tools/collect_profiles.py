@@ -30,7 +30,13 @@ for d, name in ((f"{tag}_prof", f"{tag}_kernel_stats.csv"), (f"{tag}_prof_c2", f
         open(os.path.join(out, name), "w").write(open(stats).read())
 
 
-def classify(name, game):
+SOLO_GRIDS = set()
+
+
+def classify(name, game, grid=None):
+    if "k_gemm_solo" in name:  # one template for both dense layers: fc1 (N = 1024) launches twice the workgroups of fc2 (N = 512)
+        SOLO_GRIDS.add(int(grid or 0))
+        return ("k_gemm_fc1", "k_gemm_fc2", int(grid or 0))
     if "k_trunk" in name:
         return "k_trunk"
     if "k_heads" in name:
@@ -48,13 +54,25 @@ def classify(name, game):
 def averages(d, game):
     """{(kernel class, counter): (mean value, mean duration ns, dispatches)} of one counter pass"""
     f = find(d, "counter_collection.csv")
-    acc = {}
+    acc, pending = {}, []
     if not f:
         return acc
+    SOLO_GRIDS.clear()
     for row in csv.DictReader(open(f)):
-        k = classify(row["Kernel_Name"], game)
+        k = classify(row["Kernel_Name"], game, row.get("Grid_Size"))
         if k is None:
             continue
+        if isinstance(k, tuple):
+            pending.append((k, row))
+            continue
+        dur = None
+        if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+            dur = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        a = acc.setdefault((k, row["Counter_Name"]), [0.0, 0.0, 0])
+        a[0] += float(row["Counter_Value"]); a[1] += dur or 0.0; a[2] += 1
+    big = max(SOLO_GRIDS) if SOLO_GRIDS else 0
+    for (k1, k2, grid), row in pending:  # k_gemm_solo: the larger grid is fc1 (when only one grid size ran solo it is fc1: fc2 needs 32768 rows)
+        k = k1 if grid == big else k2
         dur = None
         if row.get("Start_Timestamp") and row.get("End_Timestamp"):
             dur = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])

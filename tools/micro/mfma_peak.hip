@@ -1,70 +1,58 @@
-// Ceiling check for the f32 matrix pipe on gfx950: independent v_mfma chains with no memory traffic at all.
-// build + run on the GPU box: hipcc -O3 --offload-arch=gfx950 -o /tmp/mfma_peak tools/micro/mfma_peak.hip && /tmp/mfma_peak
-// Prints TFLOP/s for 32x32x2 and 16x16x4 f32 at 1 and 2 waves per SIMD and NACC independent accumulators per wave.
+// Micro-benchmark: what do the f32-input MFMA shapes sustain on this chip for kernel durations like ours
+// (tens of microseconds), with 1/2/4 waves per SIMD?  Pure register loop, no memory traffic.
 #include <hip/hip_runtime.h>
-#include <cstdio>
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int NACC>
-__global__ __launch_bounds__(256) void k32(float *out, int iters, float a, float b) {
-    f32x16 acc[NACC];
-    for (int i = 0; i < NACC; ++i)
-        for (int r = 0; r < 16; ++r) acc[i][r] = (float)(threadIdx.x + i);
+__global__ __launch_bounds__(256) void k16(float *out, int iters, float a0, float b0) {
+    f32x4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0, 0, 0, 0};
+    float a = a0 + threadIdx.x * 1e-3f, b = b0 + threadIdx.x * 2e-3f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
     }
     float s = 0;
-    for (int i = 0; i < NACC; ++i)
-        for (int r = 0; r < 16; ++r) s += acc[i][r];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 template <int NACC>
-__global__ __launch_bounds__(256) void k16(float *out, int iters, float a, float b) {
-    f32x4 acc[NACC];
-    for (int i = 0; i < NACC; ++i)
-        for (int r = 0; r < 4; ++r) acc[i][r] = (float)(threadIdx.x + i);
+__global__ __launch_bounds__(256) void k32(float *out, int iters, float a0, float b0) {
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+    float a = a0 + threadIdx.x * 1e-3f, b = b0 + threadIdx.x * 2e-3f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
     }
     float s = 0;
-    for (int i = 0; i < NACC; ++i)
-        for (int r = 0; r < 4; ++r) s += acc[i][r];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    for (int i = 0; i < NACC; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 template <typename F>
-static void run(const char *name, F launch, double flop_per_wave_iter, int blocks, int iters) {
+void run(const char *name, F launch, double flops_per_iter_per_wave) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    launch(blocks, iters / 8);
-    hipDeviceSynchronize();
-    hipEventRecord(e0);
-    launch(blocks, iters);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    double flops = flop_per_wave_iter * iters * blocks * 4.0;
-    printf("%-34s blocks %5d  %8.3f ms  %7.1f TFLOP/s\n", name, blocks, ms, flops / ms * 1e-9);
+    for (int bpc = 1; bpc <= 4; bpc *= 2)
+        for (int iters : {600, 6000}) {
+            int grid = 256 * bpc, it = iters / bpc;
+            for (int rep = 0; rep < 3; ++rep) launch(grid, it);
+            hipEventRecord(e0);
+            const int reps = 20;
+            for (int rep = 0; rep < reps; ++rep) launch(grid, it);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            double flops = (double)grid * 4 * it * flops_per_iter_per_wave;
+            printf("%s waves/SIMD %d iters %5d : %7.1f us, %.1f TFLOP/s\n", name, bpc, it, ms / reps * 1e3, flops / (ms / reps * 1e-3) / 1e12);
+        }
 }
 int main() {
-    float *out; hipMalloc(&out, 4096 * 256 * 4);
-    const int iters = 20000;
-    // 32x32x2: 4096 flop per instruction; 4 x NACC instructions per loop iteration
-#define R32(N, BLK) run("32x32x2 f32 NACC=" #N, [&](int b, int it) { hipLaunchKernelGGL((k32<N>), dim3(b), dim3(256), 0, 0, out, it, 1.0f, 0.5f); }, 4096.0 * 4 * N, BLK, iters);
-#define R16(N, BLK) run("16x16x4 f32 NACC=" #N, [&](int b, int it) { hipLaunchKernelGGL((k16<N>), dim3(b), dim3(256), 0, 0, out, it, 1.0f, 0.5f); }, 2048.0 * 4 * N, BLK, iters);
-    printf("-- one wave per SIMD (256 blocks of 4 waves)\n");
-    R32(1, 256) R32(2, 256) R32(4, 256) R32(8, 256) R32(16, 256)
-    R16(4, 256) R16(8, 256) R16(16, 256)
-    printf("-- two waves per SIMD (512 blocks)\n");
-    R32(4, 512) R32(8, 512)
-    R16(8, 512)
-    printf("-- four waves per SIMD (1024 blocks)\n");
-    R32(4, 1024)
+    float *out;
+    hipMalloc(&out, sizeof(float) * 256 * 4096);
+    run("16x16x4 x8acc", [&](int g, int it) { hipLaunchKernelGGL(k16<8>, dim3(g), dim3(256), 0, 0, out, it, 1.0f, 0.5f); }, 8 * 2048.0);
+    run("16x16x4 x2acc", [&](int g, int it) { hipLaunchKernelGGL(k16<2>, dim3(g), dim3(256), 0, 0, out, it * 4, 1.0f, 0.5f); }, 4 * 2 * 2048.0);
+    run("32x32x2 x4acc", [&](int g, int it) { hipLaunchKernelGGL(k32<4>, dim3(g), dim3(256), 0, 0, out, it, 1.0f, 0.5f); }, 4 * 4096.0);
+    run("32x32x2 x1acc", [&](int g, int it) { hipLaunchKernelGGL(k32<1>, dim3(g), dim3(256), 0, 0, out, it * 4, 1.0f, 0.5f); }, 4 * 4096.0);
     return 0;
 }
