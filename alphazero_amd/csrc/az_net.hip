@@ -1266,6 +1266,139 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 
+// k_gemm_solo's scheme for row counts that do not fill the chip with 256x256 tiles (fc1 at 8192 rows, fc2 at 16384): waves of
+// 32 TM x 32 TN (2 x 2 waves per workgroup, tile 64 TM x 64 TN), the same hand-placed k-steps -- in front of the TN MFMAs of "quarter"
+// tm one A and TN / TM B fragment reads of the next k-step and ONE staging instruction: the next K tile's NA + NB global loads from
+// k-step 0 on, its LDS stores from k-step 8 on.  Instantiated for (TM, TN) = (2, 2): 128x128 tiles, two workgroups per CU (66 KB of
+// LDS each), i.e. two waves per SIMD.  Same accumulation chain.
+template <bool RELU, int TM, int TN>
+__global__ __launch_bounds__(256) void k_gemm_solo_t(const float *__restrict__ A, const float *__restrict__ Bw, const float *__restrict__ bias,
+                                                     float *__restrict__ C, int M, int N, int K, const int *__restrict__ dyn_count) {
+    if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, ASTR = BK + 1, BSTR = BN;
+    constexpr int NA = 2 * TM, NB = 2 * TN, NL = NA + NB, BQ = BN / 4, BROWS = 256 / BQ, BPQ = TN / TM;
+    static_assert(TN % TM == 0 && NL <= 8 * TM && BQ <= 256 && 256 % BQ == 0, "staging plan: loads in k-steps 0-7, stores in 8-15");
+    const int nbx = N / BN, nb = nbx * (int)gridDim.y;
+    int bid = (int)blockIdx.y * nbx + (int)blockIdx.x;
+    if (nb % 8 == 0) bid = (bid % 8) * (nb / 8) + bid / 8;  // XCD-aware tile order, as k_gemm
+    const int tile_y = bid / nbx, tile_x = bid % nbx;
+    if (tile_y * BM >= M) return;
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float *As = gsm;                  // [2][BM][ASTR]
+    float *Bs = gsm + 2 * BM * ASTR;  // [2][BK][BSTR]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave >> 1) * 32 * TM, wn0 = (wave & 1) * 32 * TN;
+    const int bm0 = tile_y * BM, bn0 = tile_x * BN;
+    f32x16 acc[TM][TN];
+    {   // bias through the matrix pipe, as k_gemm_solo
+        const float one = lane < 32 ? 1.0f : 0.0f;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const float bv = lane < 32 ? bias[bn0 + wn0 + tn * 32 + lane] : 0.0f;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                acc[tm][tn] = MFMA32(one, bv, z);
+            }
+        }
+    }
+    const int arow = tid >> 3, aq = tid & 7, brow = tid / BQ, bc4 = tid % BQ;
+    static_assert(NA <= 4, "A staging slots");
+    unsigned aoff0 = 0, aoff1 = 0, aoff2 = 0, aoff3 = 0;
+#define T_SETOFF(i, var)                                                   \
+    if ((i) < NA) {                                                        \
+        int gr = bm0 + arow + 32 * (i);                                    \
+        gr = gr < M ? gr : M - 1;                                          \
+        var = (unsigned)(((size_t)gr * K + 4 * aq) * sizeof(float));       \
+    }
+    T_SETOFF(0, aoff0) T_SETOFF(1, aoff1) T_SETOFF(2, aoff2) T_SETOFF(3, aoff3)
+#undef T_SETOFF
+    const unsigned boff = (unsigned)(((size_t)brow * N + 4 * bc4) * sizeof(float));
+    const float *Bt = Bw + bn0;
+    // staging registers by NAME (slot p < NA: A float4 #p, else B float4 #(p - NA)): register arrays indexed through the slot
+    // arithmetic were left in scratch for some (TM, TN)
+    float4 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7, sr8, sr9, sr10, sr11;
+    static_assert(NL <= 12, "staging registers");
+#define T_SR(p) ((p) == 0 ? sr0 : (p) == 1 ? sr1 : (p) == 2 ? sr2 : (p) == 3 ? sr3 : (p) == 4 ? sr4 : (p) == 5 ? sr5 : (p) == 6 ? sr6 : (p) == 7 ? sr7 : (p) == 8 ? sr8 : (p) == 9 ? sr9 : (p) == 10 ? sr10 : sr11)
+#define T_AOFF(p) ((p) == 0 ? aoff0 : (p) == 1 ? aoff1 : (p) == 2 ? aoff2 : aoff3)
+#define T_LD(p, k0)                                                                                                                          \
+    {                                                                                                                                        \
+        if ((p) < NA) T_SR(p) = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(A + (k0)) + T_AOFF(p));                     \
+        else T_SR(p) = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Bt + (size_t)((k0) + BROWS * ((p) - NA)) * N) + boff); \
+    }
+#define T_ST(p, as_, bs_)                                                                        \
+    {                                                                                            \
+        const float4 v = T_SR(p);                                                                \
+        if ((p) < NA) {                                                                          \
+            float *d = (as_) + 32 * (p) * ASTR;                                                  \
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;                                      \
+        } else {                                                                                 \
+            *reinterpret_cast<float4 *>((bs_) + BROWS * ((p) - NA) * BSTR) = v;                  \
+        }                                                                                        \
+    }
+#define T_FENCE() { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define T_COMPUTE(buf, NEXT, k0n)                                                                                \
+    {                                                                                                            \
+        const float *as = As + (buf) * BM * ASTR + (wm0 + (lane & 31)) * ASTR + (lane >> 5);                     \
+        const float *bs = Bs + (buf) * BK * BSTR + (lane >> 5) * BSTR + wn0 + (lane & 31);                       \
+        float *as_ = As + ((buf) ^ 1) * BM * ASTR + arow * ASTR + 4 * aq, *bs_ = Bs + ((buf) ^ 1) * BK * BSTR + brow * BSTR + 4 * bc4; \
+        float afr[2][TM], bfr[2][TN];                                                                            \
+        _Pragma("unroll") for (int x = 0; x < TM; ++x) afr[0][x] = as[x * 32 * ASTR];                            \
+        _Pragma("unroll") for (int x = 0; x < TN; ++x) bfr[0][x] = bs[x * 32];                                   \
+        _Pragma("unroll") for (int ks = 0; ks < BK / 2; ++ks) {                                                  \
+            _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {                                                  \
+                if (ks + 1 < BK / 2) {                                                                           \
+                    afr[(ks + 1) & 1][tm] = as[tm * 32 * ASTR + (ks + 1) * 2];                                   \
+                    _Pragma("unroll") for (int j = 0; j < BPQ; ++j)                                              \
+                        bfr[(ks + 1) & 1][tm * BPQ + j] = bs[(ks + 1) * 2 * BSTR + (tm * BPQ + j) * 32];         \
+                }                                                                                                \
+                if (NEXT) {                                                                                      \
+                    const int pl = ks * TM + tm, ps = (ks - 8) * TM + tm;                                        \
+                    if (pl < NL) T_LD(pl, k0n)                                                                   \
+                    if (ks >= 8 && ps < NL) T_ST(ps, as_, bs_)                                                   \
+                }                                                                                                \
+                T_FENCE()                                                                                        \
+                _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA32(afr[ks & 1][tm], bfr[ks & 1][tn], acc[tm][tn]); \
+                T_FENCE()                                                                                        \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+    const int T = K / BK;
+#pragma unroll
+    for (int p = 0; p < NL; ++p) T_LD(p, 0)
+    {
+        float *as_ = As + arow * ASTR + 4 * aq, *bs_ = Bs + brow * BSTR + 4 * bc4;
+#pragma unroll
+        for (int p = 0; p < NL; ++p) T_ST(p, as_, bs_)
+    }
+    __syncthreads();
+    for (int t = 0; t + 1 < T; ++t) {  // the last tile is peeled: no conditional staging inside the loop
+        T_COMPUTE(t & 1, true, (t + 1) * BK)
+        __syncthreads();
+    }
+    T_COMPUTE((T - 1) & 1, false, 0)
+#undef T_LD
+#undef T_ST
+#undef T_SR
+#undef T_AOFF
+#undef T_FENCE
+#undef T_COMPUTE
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = bn0 + wn0 + tn * 32 + (lane & 31);
+                float v = acc[tm][tn][r];
+                if (RELU) v = v > 0.0f ? v : 0.0f;
+                if (row < M) C[(size_t)row * N + col] = v;
+            }
+}
+
 // Dense layer for a handful of rows (single-game search, small arenas): one wavefront per (row, 64 output columns),
 // plain fmaf in k order -- the same chain the MFMA tiles compute, so the results are bit-identical -- with 16 to 32 weight
 // loads in flight per lane.  The tiled GEMM walks its K tiles serially inside one workgroup (~1 us per tile whatever the
@@ -2342,6 +2475,21 @@ static int gemm_go(const float *A, const float *Bw, const float *bias, float *C,
     }
 }
 
+template <int TM, int TN>
+static int solo_t_launch(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, lds = 4 * (2 * BM * 33 + 2 * 32 * BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_solo_t<true, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_solo_t<false, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    dim3 grid(N / BN, (M + BM - 1) / BM);
+    if (relu) hipLaunchKernelGGL((k_gemm_solo_t<true, TM, TN>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+    else hipLaunchKernelGGL((k_gemm_solo_t<false, TM, TN>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+    return AZ_OK;
+}
+
 static int launch_gemm(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
     AZ_REQUIRE(K % 32 == 0, AZ_EINVAL, "GEMM K=%d is not a multiple of 32", K);
     // measured crossover against the tiled GEMM (MI355X): K = 512 up to 128 rows (15 vs 21 us), K = 1024 up to 256 rows (28 vs 40 us)
@@ -2367,6 +2515,14 @@ static int launch_gemm(const float *A, const float *Bw, const float *bias, float
             if (relu) hipLaunchKernelGGL((k_gemm_solo<true>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
             else hipLaunchKernelGGL((k_gemm_solo<false>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
             return AZ_OK;
+        }
+        // below that: the same scheme on 128x128 tiles from TWO tiles per CU up (fc1 from 8192 rows, fc2 from 16384; AZ_GEMM_SOLO=2
+        // forces it).  Measured against k_gemm: 76 vs 80 us (fc1, 8192 rows), 137 vs 144 (fc2, 16384); with ONE tile per CU it loses
+        // (4096 rows: 42.6 vs 41.4 us, 64x128 tiles 57 vs 42): a 4096-cycle K tile does not carry its barrier and LDS turnaround
+        // without a partner wave, and k_gemm's two blocks per CU are exactly that partner.
+        if (solo != 0 && solo != 1 && N % 128 == 0) {
+            const long long t128 = (long long)((M + 127) / 128) * (N / 128);
+            if (solo == 2 || (solo < 0 && t128 >= 512)) return solo_t_launch<2, 2>(A, Bw, bias, C, M, N, K, relu, dyn, st);
         }
     }
     // pick the largest tile that still gives every CU two resident blocks (512 blocks on 256 CUs):

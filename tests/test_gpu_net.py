@@ -75,7 +75,8 @@ def test_large_batch_kernel_equals_small_batch_kernel(tag):
     wave on 16x16x4: same accumulation order, so the same boards must give the same bits in either -- odd and ragged
     batch sizes included (the small-batch results are the ones checked against the oracle above).  The dense layers
     switch tile shapes with the batch as well (128x128 from 8192 / 16384 rows; the one-wave-per-SIMD k_gemm_solo with 256x256
-    workgroup tiles from one tile per CU up: 16384 rows for fc1, 32768 for fc2)."""
+    workgroup tiles from one tile per CU up: 16384 rows for fc1, 32768 for fc2; its 128x128 sibling k_gemm_solo_t from two
+    tiles per CU up: fc1 at 9000 rows, fc2 at 16500)."""
     game, gid, H, W, A, n = TAGS[tag]
     fx, sd, onet, _ = nets(tag)
     sizes = (4096, 4099, 6001, 9000) + ((16500, 33000) if tag == "othello8" else ())  # 16500: fc1 on k_gemm_solo, fc2 on the 128x128 tile; 33000: both solo
