@@ -1105,7 +1105,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int bid = (int)blockIdx.y * nbx + (int)blockIdx.x;
     if (nb % 8 == 0) bid = (bid % 8) * (nb / 8) + bid / 8;  // XCD-aware tile order, as k_gemm
     const int tile_y = bid / nbx, tile_x = bid % nbx;
-    if (tile_y * BM >= M) return;
+    // The grid is sized for the launch's capacity; the rows really present (dyn_count) may be far fewer -- the last plies of a
+    // self-play wave evaluate a few hundred leaves.  A 256-row tile would then leave most CUs idle while a few grind through whole
+    // tiles, so the tile HEIGHT follows the rows: 64 or 128 rows per workgroup (one or two 32-row tiles per wave instead of four)
+    // as soon as the grid has enough workgroups for that many row tiles.  Columns, staging and the K loop are unchanged.
+    int tme = 4;
+    if ((M + 63) / 64 <= (int)gridDim.y) tme = 1;
+    else if ((M + 127) / 128 <= (int)gridDim.y) tme = 2;
+    const int BMe = 64 * tme;
+    if (tile_y * BMe >= M) return;
 #ifdef AZ_PROBE
     unsigned long long pk0, pk1, pl0, pl1;
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -1115,8 +1123,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float *As = gsm;                  // [2][BM][ASTR]
     float *Bs = gsm + 2 * BM * ASTR;  // [2][BK][BSTR]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 128;
-    const int bm0 = tile_y * BM, bn0 = tile_x * BN;
+    const int wm0 = (wave >> 1) * 32 * tme, wn0 = (wave & 1) * 128;
+    const int bm0 = tile_y * BMe, bn0 = tile_x * BN;
     // accumulators start at the bias THROUGH the matrix pipe (1 * bias[col] + 0 * 0 on a zero accumulator: exact): a plain splat of
     // four bias values over 256 registers makes the compiler hold a second copy of them and spill (measured: 100 dwords)
     f32x16 acc[4][4];
@@ -1176,18 +1184,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // staging instruction in front of every group of four MFMAs, fenced so that the scheduler does not gather them again.
     // scheduling fence that instruction selection honours too: a plain sched_barrier left the LDS reads free to gather ahead of it
 #define SOLO_FENCE() { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#define SOLO_COMPUTE(buf, NEXT, k0n)                                                                             \
+#define SOLO_COMPUTE(buf, NEXT, k0n, TME)                                                                            \
     {                                                                                                            \
         const float *as = As + (buf) * BM * ASTR + (wm0 + (lane & 31)) * ASTR + (lane >> 5);                     \
         const float *bs = Bs + (buf) * BK * BSTR + (lane >> 5) * BSTR + wn0 + (lane & 31);                       \
         float *as_ = As + ((buf) ^ 1) * BM * ASTR + arow * ASTR + 4 * aq, *bs_ = Bs + ((buf) ^ 1) * BK * BSTR + (tid >> 6) * BSTR + 4 * (tid & 63); \
         float afr[2][4], bfr[2][4];                                                                              \
-        _Pragma("unroll") for (int x = 0; x < 4; ++x) { afr[0][x] = as[x * 32 * ASTR]; bfr[0][x] = bs[x * 32]; } \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) { if (x < TME) afr[0][x] = as[x * 32 * ASTR]; bfr[0][x] = bs[x * 32]; } \
         _Pragma("unroll") for (int ks = 0; ks < BK / 2; ++ks) {                                                  \
             _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) {                                                   \
                 /* quarter tm of the k-step: two fragment reads of step ks + 1 and one staging instruction, then 4 MFMAs */ \
                 if (ks + 1 < BK / 2) {                                                                           \
-                    afr[(ks + 1) & 1][tm] = as[tm * 32 * ASTR + (ks + 1) * 2];                                   \
+                    if (tm < TME) afr[(ks + 1) & 1][tm] = as[tm * 32 * ASTR + (ks + 1) * 2];                     \
                     bfr[(ks + 1) & 1][tm] = bs[(ks + 1) * 2 * BSTR + tm * 32];                                   \
                 }                                                                                                \
                 if (NEXT && tm == 0) {                                                                           \
@@ -1227,7 +1235,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if (ks == 15) SOLO_STB(7, bs_)                                                               \
                 }                                                                                                \
                 SOLO_FENCE()                                                                                     \
-                _Pragma("unroll") for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = MFMA32(afr[ks & 1][tm], bfr[ks & 1][tn], acc[tm][tn]); \
+                if (tm < TME) {                                                                                  \
+                    _Pragma("unroll") for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = MFMA32(afr[ks & 1][tm], bfr[ks & 1][tn], acc[tm][tn]); \
+                }                                                                                                \
                 SOLO_FENCE()                                                                                     \
             }                                                                                                    \
         }                                                                                                        \
@@ -1237,25 +1247,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     SOLO_STASH(0)
     __syncthreads();
     STAMP(pl0)
-    for (int t = 0; t + 1 < T; ++t) {  // the last tile is peeled: no conditional staging inside the loop
-        SOLO_COMPUTE(t & 1, true, (t + 1) * BK)
-        __syncthreads();
+    // C/D layout of 32x32x2: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Inside each copy of the loop:
+    // a common epilogue behind the three copies makes the compiler shuffle the 256 accumulators at the join.
+#define SOLO_EPILOGUE(TME)                                                                                       \
+    _Pragma("unroll") for (int tm = 0; tm < TME; ++tm) _Pragma("unroll") for (int tn = 0; tn < 4; ++tn)          \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                         \
+            const int row = bm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);                      \
+            const int col = bn0 + wn0 + tn * 32 + (lane & 31);                                                   \
+            float v = acc[tm][tn][r];                                                                            \
+            if (RELU) v = v > 0.0f ? v : 0.0f;                                                                   \
+            if (row < M) C[(size_t)row * N + col] = v;                                                           \
+        }
+    // the last tile is peeled: no conditional staging inside the loop; one copy of the loop per tile height (compile-time TME)
+#define SOLO_MAIN(TME)                                       \
+    {                                                        \
+        for (int t = 0; t + 1 < T; ++t) {                    \
+            SOLO_COMPUTE(t & 1, true, (t + 1) * BK, TME)     \
+            __syncthreads();                                 \
+        }                                                    \
+        STAMP(pl1)                                           \
+        SOLO_COMPUTE((T - 1) & 1, false, 0, TME)             \
+        SOLO_EPILOGUE(TME)                                   \
     }
-    STAMP(pl1)
-    SOLO_COMPUTE((T - 1) & 1, false, 0)
-    // C/D layout of 32x32x2: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = bm0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = bn0 + wn0 + tn * 32 + (lane & 31);
-                float v = acc[tm][tn][r];
-                if (RELU) v = v > 0.0f ? v : 0.0f;
-                if (row < M) C[(size_t)row * N + col] = v;
-            }
+    if (tme == 4) SOLO_MAIN(4)
+    else if (tme == 2) SOLO_MAIN(2)
+    else SOLO_MAIN(1)
+#undef SOLO_MAIN
+#undef SOLO_EPILOGUE
 #ifdef AZ_PROBE
     STAMP(pk1)
     if (tid == 0) {  // shader-clock cycles of the whole block and of its main loop, the 100 MHz real-time clock over the same span

@@ -139,6 +139,20 @@ class HipNet:
         check(lib().az_net_forward(self.h, x.data_ptr(), B, probs.data_ptr(), v.data_ptr(), _stream_ptr()))
         return probs, v
 
+    def forward_dyn(self, x, count, probs=None, v=None):
+        """az_net_forward_dyn: evaluates only the first min(count[0], B) rows of x; `count` is an int32 CUDA tensor (the engine's
+        leaf counter on the hot path: the launch is sized for B, the rows really present are read on the device).  Rows beyond
+        the count are left as they were in `probs` / `v`."""
+        x = x.contiguous().view(-1, self.H * self.W)
+        assert x.is_cuda and x.dtype == torch.float32 and count.is_cuda and count.dtype == torch.int32
+        B = x.shape[0]
+        if probs is None:
+            probs = torch.empty((B, self.A), dtype=torch.float32, device=x.device)
+        if v is None:
+            v = torch.empty(B, dtype=torch.float32, device=x.device)
+        check(lib().az_net_forward_dyn(self.h, x.data_ptr(), count.data_ptr(), B, probs.data_ptr(), v.data_ptr(), _stream_ptr()))
+        return probs, v
+
     def flops_per_board(self):
         return int(lib().az_net_flops_per_board(self.h))
 

@@ -94,6 +94,31 @@ def test_large_batch_kernel_equals_small_batch_kernel(tag):
         assert torch.equal(p, p_ref[idx]) and torch.equal(v, v_ref[idx]), (tag, B)
 
 
+def test_dynamic_row_counts_on_a_launch_sized_for_the_full_batch():
+    """the hot path's form of the call (az_net_forward_dyn): the launch is sized for the engine's capacity, the rows really present
+    are a device counter.  Towards the end of a self-play wave the counter falls to a few hundred rows on a 32768-row launch: the
+    dense kernel then lowers its tile height (k_gemm_solo: 64 / 128 / 256 rows per workgroup), the persistent trunk and the heads
+    stop at the counter.  Every count must give the bits of the plain forward on the same rows and leave the rows behind it alone."""
+    game, gid, H, W, A, n = TAGS["othello8"]
+    fx, sd, onet, _ = nets("othello8")
+    cap = 33000
+    hnet = E.HipNet(gid, H, W, sd, max_batch=cap)
+    grids, players, _ = O.random_positions(gid, H, W, 12, 40, 1200)
+    canon = torch.as_tensor((grids * players[:, None]).astype(np.float32), device="cuda")
+    n0 = canon.shape[0]
+    p_ref, v_ref = hnet.forward(canon)  # small-batch kernels: the results checked against the oracle elsewhere in this file
+    idx = (torch.arange(cap, device="cuda") * 5 + 1) % n0
+    x = canon[idx].contiguous()
+    for count in (0, 1, 63, 64, 65, 500, 4097, 8192, 8193, 12000, 16384, 16385, 20000, 32768, 33000, 40000):
+        c = torch.tensor([count], dtype=torch.int32, device="cuda")
+        probs = torch.full((cap, A), -7.0, device="cuda")
+        v = torch.full((cap,), -7.0, device="cuda")
+        hnet.forward_dyn(x, c, probs, v)
+        m = min(count, cap)
+        assert torch.equal(probs[:m], p_ref[idx[:m]]) and torch.equal(v[:m], v_ref[idx[:m]]), count
+        assert bool((probs[m:] == -7.0).all()) and bool((v[m:] == -7.0).all()), count
+
+
 def test_live_stage_profile():
     """az_net_profile: HIP events around every stage launch; the counts tell which trunk kernel served which batch"""
     game, gid, H, W, A, n = TAGS["othello8"]
