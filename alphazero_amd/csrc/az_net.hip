@@ -1091,8 +1091,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const float *__restrict__ A, co
 // k_gemm's 64x64 per wave this halves the LDS fragment reads and the barriers per MFMA (16 MFMAs per 8 fragment reads, one
 // barrier per 256 MFMAs per wave) -- the two-waves-per-SIMD kernel spends 46 % of each wave's time outside its MFMA chains
 // (in-kernel stamps) and leaves the pipe idle whenever both partners are there (MFMA busy 76-80 %).  A K tile of a wave is
-// 16 k-steps x 16 MFMAs = 16 K cycles of matrix work, several times the global-memory latency: the next tile's loads are
-// issued at the top of the tile and stored to the other LDS buffer at its end, one register set, a runtime K loop.
+// 16 k-steps x 16 MFMAs = 16 K cycles of matrix work, several times the global-memory latency: one register set and a runtime
+// K loop suffice.  The next tile's loads and LDS stores ride INSIDE the k-steps (see SOLO_COMPUTE): as a block between two tiles
+// they cost 11 % of the loop (18.5 K cycles per tile against 17.3 K; tools/probe_gemm_solo.py).  Measured at 32768 rows: fc1 259,
+// fc2 248 us against k_gemm's 280 / 268; MFMA busy 0.82 / 0.86; HBM traffic 1.16x / 1.08x the algorithmic bytes (k_gemm 2.09x / 1.54x).
 // Accumulation: bias, then k ascending on v_mfma_f32_32x32x2_f32 -- the chain of k_gemm / k_dense_small / the oracle.
 // ---------------------------------------------------------------------------------------------
 template <bool RELU>
