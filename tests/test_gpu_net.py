@@ -109,7 +109,8 @@ def test_dynamic_row_counts_on_a_launch_sized_for_the_full_batch():
     p_ref, v_ref = hnet.forward(canon)  # small-batch kernels: the results checked against the oracle elsewhere in this file
     idx = (torch.arange(cap, device="cuda") * 5 + 1) % n0
     x = canon[idx].contiguous()
-    for count in (0, 1, 63, 64, 65, 500, 4097, 8192, 8193, 12000, 16384, 16385, 20000, 32768, 33000, 40000):
+    # 8256 / 8257 and 16512 / 16513: the last counts that still fit 64- / 128-row tiles into the 129 tile rows of this launch
+    for count in (0, 1, 63, 64, 65, 500, 4097, 8192, 8256, 8257, 12000, 16384, 16512, 16513, 20000, 32768, 33000, 40000):
         c = torch.tensor([count], dtype=torch.int32, device="cuda")
         probs = torch.full((cap, A), -7.0, device="cuda")
         v = torch.full((cap,), -7.0, device="cuda")
