@@ -45,6 +45,31 @@ def test_selfplay_at_baseline_simulation_counts_equals_oracle(name, gid, H, W, g
         assert np.array_equal(got[k], ref[k]), k
 
 
+@pytest.mark.parametrize("name,gid,H,W,slots,sims,picks", [("othello8", 0, 8, 8, 4096, 25, (9000, 11047, 13095)),
+                                                           ("connect4", 1, 6, 7, 4096, 40, (9000, 10021, 13095)),
+                                                           # the headline's slot count: k_gemm_solo, its tile height following the rows
+                                                           ("othello8", 0, 8, 8, 32768, 20, (9000, 25383, 41767))])
+def test_selfplay_on_the_large_batch_kernels_sampled_games_equal_oracle(name, gid, H, W, slots, sims, picks):
+    """the kernels the benchmark runs on (two-boards-per-wave trunk with the Winograd conv2, tiled GEMMs, k_heads2 / fused tail, all
+    behind the device row counter) only start at 4096 rows, where the oracle cannot follow every game.  Games are independent given
+    (seed, game id): a whole wave of 4096 (32768) games is played on the engine and three of them are replayed alone on the oracle --
+    samples, visit counts and policies of those games must be equal bit for bit."""
+    from alphazero_amd.games.connect4 import Connect4Net
+    from alphazero_amd.games.othello import OthelloNet
+    torch.manual_seed(1)
+    net = (OthelloNet(n=8) if gid == 0 else Connect4Net(7, 6)).eval()
+    onet = O.ConvNet(gid, H, W, _np_sd(net))
+    eng = E.SelfPlayEngine(gid, H, W, n_slots=slots, n_sim=sims, net=net.to_hip(max_batch=slots), seed=41)
+    got = sort_samples(eng.run(slots, first_game_id=9000))
+    assert eng.stats()["games_done"] == slots
+    for g in picks:
+        ref = O.selfplay(gid, H, W, 1, sims, ("conv", onet), seed=41, first_game_id=g)
+        rows = got["meta"][:, 0] == g
+        assert rows.sum() == len(ref["meta"]) > 0, g
+        for k in ("state", "z", "meta", "visits", "pi"):
+            assert np.array_equal(got[k][rows], ref[k]), (g, k)
+
+
 # ------------------------------------------------------------------------------------------------ ragged slot counts
 @pytest.mark.parametrize("slots", [1, 2, 3, 5, 6, 7, 13, 21, 30])
 def test_slot_counts_that_do_not_fill_a_wavefront(slots):
