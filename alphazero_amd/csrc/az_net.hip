@@ -2416,15 +2416,15 @@ static bool use_wino(int CH, int CW) {
     static int mode = -2;
     if (mode == -2) { const char *e = getenv("AZ_WINOGRAD"); mode = e ? atoi(e) : -1; }
     if (mode == 0) return false;
-    return (CH == 8 && CW == 8) || (mode == 1 && CH == 7 && CW == 6);
+    return (CH == 8 && CW == 8) || (CH == 7 && CW == 6);  // AZ_WINOGRAD=0: direct form everywhere (the oracle follows the same variable)
 }
 
 template <int CH, int CW, bool WINO>
 static int launch_trunk2(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
     using G = TrunkGeom<CH, CW>;
-    // one workgroup per CU, two boards per wave: two waves per SIMD -- or, for the Winograd conv2 of 8x8 planes, ONE wave per SIMD
-    // with 512 registers (all 16 frequency accumulators live) and the transformed weights in the LDS the other four waves would use
-    constexpr int WPB = (WINO && CH == 8 && CW == 8) ? 4 : 8;
+    // one workgroup per CU, two boards per wave: two waves per SIMD -- or, for the Winograd conv2 (8x8 and 7x6 planes), ONE wave per
+    // SIMD with 512 registers (all 16 frequency accumulators live) and the transformed weights in the LDS the other four waves would use
+    constexpr int WPB = WINO ? 4 : 8;
     constexpr int lds_planes = 64 + WPB * 2 * G::WAVE_FLOATS * 4;
     constexpr int lds_bytes = lds_planes + ((WINO && lds_planes + 65536 <= 160 * 1024) ? 65536 : 0);  // + the Winograd U fragments where they fit
     static_assert(lds_bytes <= 160 * 1024, "k_trunk2 workgroup does not fit the CU's LDS");

@@ -48,11 +48,11 @@ def stage_flops(CH, CW, F1, F2, A):
 
 
 def executed_conv_flops(CH, CW):
-    """FLOPs the trunk kernel EXECUTES per board on the matrix cores: conv2 of 8x8 planes runs in the Winograd F(2x2,3x3)
-    form (16 tiles x 16 frequencies x 32 x 32 MACs instead of 64 x 9 x 32 x 32; AZ_WINOGRAD=0 switches it off) -- the SURVEY's
+    """FLOPs the trunk kernel EXECUTES per board on the matrix cores: conv2 of 8x8 and 7x6 planes runs in the Winograd F(2x2,3x3)
+    form (tiles x 16 frequencies x 32 x 32 MACs instead of positions x 9 x 32 x 32; AZ_WINOGRAD=0 switches it off) -- the SURVEY's
     algorithmic figure stays the numerator of `frac`, this one is reported beside it"""
     p1, p3, p4 = CH * CW, (CH - 2) * (CW - 2), (CH - 4) * (CW - 4)
-    wino = (CH, CW) == (8, 8) and os.environ.get("AZ_WINOGRAD", "") != "0" or (CH, CW) == (7, 6) and os.environ.get("AZ_WINOGRAD", "") == "1"
+    wino = (CH, CW) in ((8, 8), (7, 6)) and os.environ.get("AZ_WINOGRAD", "") != "0"
     conv2 = ((CH + 1) // 2) * ((CW + 1) // 2) * 16 * 32 * 32 if wino else p1 * 9 * 32 * 32
     return 2 * (p1 * 9 * 32 + conv2 + p3 * 9 * 32 * 32 + p4 * 9 * 32 * 32), wino
 

@@ -416,10 +416,10 @@ orc_convnet *orc_convnet_create(int game, int H, int W) {
     if (game == ORC_OTHELLO) { n->ch = H; n->cw = W; n->A = H * W + 1; n->F1 = 1024; n->F2 = 512; }
     else { n->ch = W; n->cw = H; n->A = W; n->F1 = 64; n->F2 = 32; } /* connect4.py:360-365,399 */
     {   /* the product's policy (use_wino in az_net.hip), followed here so that the two stay bit-equal: conv2 in the Winograd form on
-           8x8 planes by default, on 7x6 planes with AZ_WINOGRAD=1, nowhere with AZ_WINOGRAD=0 */
+           8x8 and 7x6 planes by default, nowhere with AZ_WINOGRAD=0 */
         const char *e = getenv("AZ_WINOGRAD");
         const int mode = e ? atoi(e) : -1;
-        n->wino = mode != 0 && ((n->ch == 8 && n->cw == 8) || (mode == 1 && n->ch == 7 && n->cw == 6));
+        n->wino = mode != 0 && ((n->ch == 8 && n->cw == 8) || (n->ch == 7 && n->cw == 6));
     }
     n->FIN = NCH * (n->ch - 4) * (n->cw - 4);
     return n;
@@ -576,7 +576,7 @@ static void conv_layer(const float *in, int IC, int ih, int iw, int pad, const f
 }
 
 /* conv2 ("same", 32 -> 32) in the Winograd F(2x2,3x3) form: the arithmetic of the HIP trunk kernels' Winograd conv2 path
- * (experimental, AZ_WINOGRAD=1: 8x8 and 7x6 planes; 2.25x fewer multiplications).  Per 2x2 output tile with its zero-padded 4x4 input patch d (per input channel):
+ * (8x8 and 7x6 planes unless AZ_WINOGRAD=0; 2.25x fewer multiplications on full tiles).  Per 2x2 output tile with its zero-padded 4x4 input patch d (per input channel):
  *   V = B^T d B      T[0]=d[0]-d[2], T[1]=d[1]+d[2], T[2]=d[2]-d[1], T[3]=d[1]-d[3] (rows), then the same on the columns of T
  *   M[f][oc] = sum over ic ASCENDING of fmaf(V[f][ic], U[f][ic][oc], M) from 0, for each of the 16 frequencies f = 4 i + j
  *   Y = A^T M A      first along the columns of M: R[i][0]=(M[i][0]+M[i][1])+M[i][2], R[i][1]=(M[i][1]-M[i][2])-M[i][3],

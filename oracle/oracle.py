@@ -196,7 +196,7 @@ class ConvNet:
         return probs, v
 
     def set_winograd(self, on):
-        """conv2 in the Winograd F(2x2,3x3) form (the product's experimental AZ_WINOGRAD=1 path) or as a direct convolution"""
+        """conv2 in the Winograd F(2x2,3x3) form (the product's default on 8x8 and 7x6 planes) or as a direct convolution (AZ_WINOGRAD=0)"""
         lib().orc_convnet_set_winograd(self.h, 1 if on else 0)
 
     def winograd(self):

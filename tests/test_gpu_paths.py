@@ -284,11 +284,10 @@ def test_plane_shapes_without_a_trunk_kernel_are_refused():
     E.lib().az_net_destroy(h)
 
 
-@pytest.mark.parametrize("mode,tags", [("1", "othello8 connect4"), ("0", "othello8")])
+@pytest.mark.parametrize("mode,tags", [("1", "othello8 connect4"), ("0", "othello8 connect4")])
 def test_both_forms_of_conv2_are_bit_equal_to_their_oracle_forms(mode, tags):
-    """conv2 runs in the Winograd F(2x2,3x3) form on 8x8 planes by default (the rest of the suite); AZ_WINOGRAD (read once per
-    process by the library AND by the oracle) selects the other combinations: "1" adds the experimental 7x6 form, "0" runs
-    the direct form everywhere.  In a child process each: known answers within 1e-5 of the reference, the network bit-equal
+    """conv2 runs in the Winograd F(2x2,3x3) form on 8x8 and 7x6 planes by default (the rest of the suite); AZ_WINOGRAD (read once
+    per process by the library AND by the oracle) switches: "1" is the default spelled out, "0" runs the direct form everywhere.  In a child process each: known answers within 1e-5 of the reference, the network bit-equal
     to the oracle below 4096 boards (one board per wave) and above (two boards per wave), one self-play run sample for sample."""
     import os
     import subprocess

@@ -78,7 +78,7 @@ def test_philox_known_answer():
 @pytest.mark.parametrize("tag", ["othello8", "connect4"])
 def test_winograd_form_of_conv2_meets_the_reference_tolerance(tag):
     """the oracle's restatement of the product's Winograd conv2 (F(2x2,3x3), 2.25x fewer multiplications; the default on 8x8
-    planes, AZ_WINOGRAD=1 for 7x6): within the same 1e-5 of the reference's torch forward (golden G2) as the direct form, and not the
+    and 7x6 planes): within the same 1e-5 of the reference's torch forward (golden G2) as the direct form, and not the
     same bits as the direct form (the two are different arithmetic; product and oracle switch together)"""
     import ast
     from tools import closed_form as cf
@@ -87,7 +87,7 @@ def test_winograd_form_of_conv2_meets_the_reference_tolerance(tag):
     shapes = {str(k): ast.literal_eval(str(v)) for k, v in zip(fx["shape_keys"], fx["shape_vals"])}
     sd = {k: v for k, v in cf.closed_form_state_dict(shapes).items() if not k.endswith("num_batches_tracked")}
     net = O.ConvNet(gid, H, W, sd)
-    assert net.winograd() == (tag == "othello8")  # the product's default: 8x8 planes
+    assert net.winograd()  # the product's default on 8x8 and 7x6 planes
     canon = fx["grids"].astype(np.float32) * fx["players"].astype(np.float32)[:, None, None]
     net.set_winograd(False)
     p0, v0 = net.forward(canon)
