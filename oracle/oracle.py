@@ -365,16 +365,19 @@ def random_positions(game_id, H, W, seed, n_games, cap):
     return grids[:n], players[:n], actions[:n]
 
 
-def arena_games(dims, ev1, n_sim, opponent, opp_sim, seed, n_rounds, start_player=None):
+def arena_games(dims, ev1, n_sim, opponent, opp_sim, seed, n_rounds, start_player=None, rounds=None):
     """Arena.play_games (arena.py:36-185) restated on the oracle: player 1 is an AlphaZero tree (evaluator ev1, no noise,
     temperature 0: what AlphaZeroTrainer.evaluate builds, trainer.py:421-425); `opponent` is "random" / "greedy"
     (players.py:76-123), "mcts" (rollout MCTSPlayer) or another evaluator tuple.  Each side owns a tree and BOTH trees
-    receive every move (arena.py:98-99).  Returns (moves per game, winners, scores, stats dict of arena.py:141-147)."""
+    receive every move (arena.py:98-99).  Returns (moves per game, winners, scores, stats dict of arena.py:141-147).
+    `rounds`: play only these round indices of the n_rounds (rounds are independent given (seed, round)): the lists and the stats
+    then cover those rounds, in that order -- how a test follows a few games of an arena too large to replay whole."""
     from collections import defaultdict
     gid, H, W = dims
     p2_starts = [{1: False, 2: True}.get(start_player, bool(r % 2)) for r in range(n_rounds)]
     all_moves, winners, scores = [], [], []
-    for r in range(n_rounds):
+    played = list(range(n_rounds)) if rounds is None else [int(r) for r in rounds]
+    for r in played:
         side1 = -1 if p2_starts[r] else 1
         game_id = (r + seed * 100003) & 0xFFFFFFFF
         t1 = MCT(ev1, eval_method=EVAL_NEURAL, tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed, game_id=game_id)
@@ -407,13 +410,13 @@ def arena_games(dims, ev1, n_sim, opponent, opp_sim, seed, n_rounds, start_playe
         all_moves.append(moves); winners.append(w.value)
         scores.append(float("inf") if gid == TICTACTOE and sc == 32767 else sc)
     stats = {"player1": [], "player2": [], "draw": 0, "player1_starts": defaultdict(int), "player2_starts": defaultdict(int)}
-    for r in range(n_rounds):
+    for i, r in enumerate(played):
         starter = f"player{2 if p2_starts[r] else 1}_starts"
-        if winners[r] == 0:
+        if winners[i] == 0:
             stats["draw"] += 1
             stats[starter]["draw"] += 1
         else:
-            who = 1 if winners[r] == (-1 if p2_starts[r] else 1) else 2
-            stats[f"player{who}"].append(scores[r])
+            who = 1 if winners[i] == (-1 if p2_starts[r] else 1) else 2
+            stats[f"player{who}"].append(scores[i])
             stats[starter]["win" if who == (2 if p2_starts[r] else 1) else "loss"] += 1
     return all_moves, winners, scores, stats

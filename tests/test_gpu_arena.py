@@ -67,6 +67,28 @@ def test_batched_arena_network_vs_network_equals_oracle(game):
     _check(game, "network", n_rounds=16, n_sim=20, opp_sim=12, seed=5)
 
 
+@pytest.mark.parametrize("game,opponent,n_rounds,n_sim,picks", [("othello", "greedy", 8192, 20, (0, 1, 4097, 8191)),
+                                                                ("connect4", "network", 4096, 24, (0, 2049, 4095))])
+def test_large_batched_arena_sampled_rounds_equal_oracle(game, opponent, n_rounds, n_sim, picks):
+    """the arena at evaluation scale: thousands of rounds at once put the side-masked search on the large-batch network kernels
+    (two boards per wave, tiled GEMMs, device row counter).  Rounds are independent given (seed, round), so a few of them are
+    replayed alone on the oracle: same moves at every ply, same winners."""
+    seed = 11
+    net, ev1, dims = _nets(game, 20 + seed)
+    if opponent == "network":
+        net2, ev2, _ = _nets(game, 40 + seed)
+        opp_engine, opp_oracle = net2, ev2
+    else:
+        opp_engine = opp_oracle = opponent
+    arena = BatchedArena(game, net, opponent=opp_engine, n_sim=n_sim, opponent_n_sim=16, seed=seed, board_size=6)
+    stats = arena.play_games(n_rounds, return_stats=True, record_moves=True)
+    assert len(stats["player1"]) + len(stats["player2"]) + stats["draw"] == n_rounds
+    moves, winners, scores, _ = oracle_arena(dims, ev1, n_sim, opp_oracle, 16, seed, n_rounds, rounds=picks)
+    for i, g in enumerate(picks):
+        got = [int(m[g]) for m in arena.moves if m[g] >= 0]
+        assert got == moves[i], (game, opponent, g, got, moves[i])
+
+
 def test_trainer_evaluates_against_the_previous_network(tmp_path):
     """BASELINE config 5 "arena eval vs prev net": eval_opponent = "previous" plays the trained network against the one it
     replaces; "alphazero" keeps the reference's refusal (trainer.py:399-400)"""
