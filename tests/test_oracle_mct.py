@@ -107,3 +107,23 @@ def test_rollout_tictactoe_stats():
     assert abs(draw - ref_draw) < 0.12, (draw, ref_draw)
     plies = (last - first + 1).mean()
     assert abs(plies - float(fx["ttt_rollout_mean_plies"])) < 0.5
+
+
+def test_games_and_arena_rounds_are_independent_given_their_ids():
+    """what the sampled large-batch GPU tests rest on (tests/test_gpu_paths.py, test_gpu_arena.py): a game of a self-play wave and a
+    round of an arena depend on (seed, game id / round) only, so replaying one of them alone gives exactly its rows of the whole run"""
+    gid, H, W = O.TICTACTOE, 3, 3
+    whole = O.selfplay(gid, H, W, 6, 12, ("fake", None), seed=3, first_game_id=40)
+    for g in (40, 43, 45):
+        alone = O.selfplay(gid, H, W, 1, 12, ("fake", None), seed=3, first_game_id=g)
+        rows = whole["meta"][:, 0] == g
+        assert rows.sum() == len(alone["meta"]) > 0
+        for k in ("state", "z", "meta", "visits", "pi"):
+            assert np.array_equal(whole[k][rows], alone[k]), (g, k)
+    dims = (O.CONNECT4, 4, 4)
+    for opponent in ("random", "greedy", "mcts"):
+        moves, winners, scores, stats = O.arena_games(dims, ("fake", None), 10, opponent, 8, 5, 6)
+        picks = (4, 1, 5)
+        m2, w2, s2, st2 = O.arena_games(dims, ("fake", None), 10, opponent, 8, 5, 6, rounds=picks)
+        assert m2 == [moves[r] for r in picks] and w2 == [winners[r] for r in picks] and s2 == [scores[r] for r in picks]
+        assert len(st2["player1"]) + len(st2["player2"]) + st2["draw"] == len(picks)
