@@ -36,9 +36,9 @@ SYMBOLS = [
     "az_last_error", "az_version", "az_board_legal_batch", "az_board_play_batch", "az_board_status_batch",
     "az_net_create", "az_net_destroy", "az_net_set_tensor", "az_net_commit", "az_net_set_tensor_device", "az_net_commit_device", "az_net_forward", "az_net_forward_dyn",
     "az_net_action_size",
-    "az_net_flops_per_board", "az_net_time_stage", "az_net_profile", "az_net_profiling", "az_net_profile_read", "az_net_profile_overhead", "az_engine_create", "az_engine_destroy", "az_engine_run",
+    "az_net_flops_per_board", "az_net_time_stage", "az_net_stage_kernel", "az_net_profile", "az_net_profiling", "az_net_profile_read", "az_net_profile_overhead", "az_engine_create", "az_engine_destroy", "az_engine_run",
     "az_engine_get_stats", "az_engine_samples", "az_engine_set_roots", "az_engine_search", "az_engine_advance",
-    "az_engine_root_children", "az_engine_play", "az_augment_count", "az_augment",
+    "az_engine_root_children", "az_engine_nodes_used", "az_engine_grow_pools", "az_engine_play", "az_augment_count", "az_augment",
     "az_engine_set_sides", "az_engine_best_moves", "az_engine_baseline_moves", "az_engine_root_status",
 ]
 
@@ -69,6 +69,7 @@ def lib():
     L.az_net_flops_per_board.argtypes = [vp]
     L.az_net_flops_per_board.restype = i64
     L.az_net_time_stage.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_float)]
+    L.az_net_stage_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int]
     L.az_net_profile.argtypes = [vp, C.c_int]
     L.az_net_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.az_net_profile_overhead.argtypes = [vp, C.POINTER(C.c_double)]
@@ -90,8 +91,24 @@ def lib():
     L.az_augment_count.argtypes = [C.c_int, vp, i64, C.POINTER(i64), vp]
     L.az_augment.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.az_engine_root_children.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
+    L.az_engine_nodes_used.argtypes = [vp, i32, C.POINTER(i32)]
+    L.az_engine_grow_pools.argtypes = [vp, i32]
     _LIB = L
     return L
+
+
+def csrc_tree_hash():
+    """sha256[:16] over the sources libaz_amd.so is built from: counter files under profiles/ carry the hash of the tree they
+    were measured on, bench.py drops them when it differs from the running build"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(_HERE), "include", "az_amd.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def check(rc):

@@ -2,6 +2,16 @@
 from collections import defaultdict
 
 
+def _check_rounds(n_rounds, start_player):
+    """arena.py:24-34"""
+    if not isinstance(n_rounds, int) or n_rounds < 1:
+        raise ValueError("n_rounds must be a positive integer")
+    if start_player is None and n_rounds % 2 != 0:
+        raise ValueError("n_rounds must be an even number or the evaluation will be biased!")
+    if start_player is not None and start_player not in (1, 2):
+        raise ValueError("start_player must be either 1 or 2 or None (to alternate starts)")
+
+
 class Arena:
     def __init__(self, player1, player2, board):
         self.player1, self.player2, self.board = player1, player2, board
@@ -29,10 +39,7 @@ class Arena:
         return {"winner": 1 if first_won else 2, "score": score} if return_results else None
 
     def play_games(self, n_rounds, start_player=None, return_stats=False, verbose=False, call_id=None):
-        if not isinstance(n_rounds, int) or n_rounds < 1:
-            raise ValueError("n_rounds must be a positive integer")
-        if start_player not in (None, 1, 2):
-            raise ValueError("start_player must be None, 1 or 2")
+        _check_rounds(n_rounds, start_player)
         stats = {"player1": [], "player2": [], "draw": 0,
                  "player1_starts": defaultdict(int), "player2_starts": defaultdict(int)}
         for round_idx in range(n_rounds):
@@ -74,16 +81,18 @@ class BatchedArena:
                                                       board_width, board_height)
         self.nn, self.opponent, self.n_sim, self.seed = nn, opponent, n_sim, seed
         self.opponent_n_sim = opponent_n_sim if opponent_n_sim is not None else n_sim
+        self.tie_mode = None  # None: fair_max draws among equals (utils.py:28-34); tests pin it to engine.TIE_LOWEST (golden G7)
 
     def _engine(self, net, G, n_sim, seed):
         from .engine import EVAL_NET, EVAL_ROLLOUT, NOISE_OFF, TIE_RANDOM, SelfPlayEngine
         plies = 4 * self.H * self.W + 16
-        rollout = isinstance(net, str)
-        if rollout and net != "mcts":
+        from .engine import EVAL_FAKE
+        rollout, fake = net == "mcts", net == "fake"  # "fake": the closed-form test network of tools/closed_form.py (golden G3 / G7)
+        if isinstance(net, str) and not (rollout or fake):
             raise ValueError(f"player '{net}' has no search tree")
-        return SelfPlayEngine(self.gid, self.H, self.W, n_slots=G, n_sim=n_sim, net=None if rollout else net.to_hip(max_batch=G),
-                              evaluator=EVAL_ROLLOUT if rollout else EVAL_NET, dirichlet_alpha=None, dirichlet_epsilon=None, temp_max_step=-1, temp_min_step=0,
-                              tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed, max_plies=plies, sample_capacity=16)
+        return SelfPlayEngine(self.gid, self.H, self.W, n_slots=G, n_sim=n_sim, net=None if isinstance(net, str) else net.to_hip(max_batch=G),
+                              evaluator=EVAL_ROLLOUT if rollout else (EVAL_FAKE if fake else EVAL_NET), dirichlet_alpha=None, dirichlet_epsilon=None, temp_max_step=-1, temp_min_step=0,
+                              tie_mode=TIE_RANDOM if self.tie_mode is None else self.tie_mode, noise_mode=NOISE_OFF, seed=seed, max_plies=plies, sample_capacity=16)
 
     def play_games(self, n_rounds, start_player=None, return_stats=True, shard=True, record_moves=False):
         """all rounds at once.  Inside a torch.distributed job (one process per GPU) the rounds are sharded over the
@@ -95,6 +104,7 @@ class BatchedArena:
         import torch
         from collections import defaultdict
         from .dist import all_gather_rows, initialized, rank_world
+        _check_rounds(n_rounds, start_player)
         rank, world = rank_world() if shard else (0, 1)
         per = (n_rounds + world - 1) // world
         lo = min(n_rounds, rank * per)
@@ -137,7 +147,7 @@ class BatchedArena:
         e1.set_roots(grids, ones, game_ids=ids)
         e1.set_sides(side1)
         e2 = None
-        if self.opponent == "mcts" or not isinstance(self.opponent, str):
+        if self.opponent in ("mcts", "fake") or not isinstance(self.opponent, str):
             e2 = self._engine(self.opponent, G, self.opponent_n_sim, self.seed + 1)
             e2.set_roots(grids, ones, game_ids=ids)
             e2.set_sides(-side1)

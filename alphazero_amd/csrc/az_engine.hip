@@ -992,8 +992,11 @@ __global__ void k_baseline_moves(EngDev E, int kind, u32 seed, int *actions) {
         }
         n = __popcll(cand);
     }
-    Philox4 r = az_philox(seed, E.game_id[g], (u32)E.ply[g], 0xFFFEu, AZ_P_TIE_MOVE, (u32)kind);
-    int k = (int)(((u64)r.x * (u64)n) >> 32);
+    int k = 0;  // greedy under the deterministic tie-break (tests against the reference's patched fair_max): lowest action
+    if (kind == 0 || E.tie_mode == AZ_TIE_RANDOM) {
+        Philox4 r = az_philox(seed, E.game_id[g], (u32)E.ply[g], 0xFFFEu, AZ_P_TIE_MOVE, (u32)kind);
+        k = (int)(((u64)r.x * (u64)n) >> 32);
+    }
     for (int i = 0; i < k; ++i) cand &= cand - 1;
     actions[g] = az_bit_to_action(gd, __ffsll((long long)cand) - 1);
 }
@@ -1393,6 +1396,45 @@ extern "C" int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_ac
         if (h_Q) h_Q[i] = ch[i].Q;
         if (h_P) h_P[i] = ch[i].P;
     }
+    return AZ_OK;
+}
+
+// Nodes the slot's live pool holds (bump allocator top): what a caller that keeps searching one root (MCT.search called again
+// and again without a move, mcts.py:226-269) checks before the next search.
+extern "C" int az_engine_nodes_used(az_engine *e, int32_t slot, int32_t *n_nodes) {
+    AZ_REQUIRE(e && n_nodes, AZ_EINVAL, "null argument");
+    AZ_REQUIRE(slot >= 0 && slot < e->d.G, AZ_EINVAL, "slot out of range");
+    AZ_HIP(hipStreamSynchronize(e->stream));
+    AZ_HIP(hipMemcpy(n_nodes, e->d.n_nodes + slot, sizeof(int), hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+// Re-allocates the tree pools with `node_capacity` nodes each and moves every slot's trees over (node links are pool-relative).
+// The reference's tree grows without bound; here the pools are sized per search and grown on demand by the single-game MCT.
+extern "C" int az_engine_grow_pools(az_engine *e, int32_t node_capacity) {
+    AZ_REQUIRE(e, AZ_EINVAL, "null argument");
+    EngDev &d = e->d;
+    AZ_REQUIRE(node_capacity >= d.C, AZ_EINVAL, "pools can only grow (%d < %d)", node_capacity, d.C);
+    if (node_capacity == d.C) return AZ_OK;
+    AZ_TRY(enter(e));
+    const size_t rows = 2 * (size_t)d.G;
+    Node *fresh = nullptr;
+    AZ_HIP(hipMalloc((void **)&fresh, rows * (size_t)node_capacity * sizeof(Node)));
+    hipError_t er = hipMemsetAsync(fresh, 0, rows * (size_t)node_capacity * sizeof(Node), e->stream);
+    if (er == hipSuccess)
+        er = hipMemcpy2DAsync(fresh, (size_t)node_capacity * sizeof(Node), d.nodes, (size_t)d.C * sizeof(Node), (size_t)d.C * sizeof(Node), rows,
+                              hipMemcpyDeviceToDevice, e->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+    if (er != hipSuccess) { (void)hipFree(fresh); az_set_error("growing the node pools failed: %s", hipGetErrorString(er)); return AZ_EHIP; }
+    for (auto &p : e->allocs) if (p == (void *)d.nodes) p = (void *)fresh;
+    (void)hipFree(d.nodes);
+    d.nodes = fresh;
+    d.C = node_capacity;
+    e->cfg.node_capacity = node_capacity;
+    // captured searches hold the old pool pointer and capacity by value
+    for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+    e->graphs.clear();
+    e->graph_seen.clear();
     return AZ_OK;
 }
 

@@ -2406,10 +2406,10 @@ extern "C" int az_net_commit_device(az_net *n, void *stream) {
 //     one-wave-per-SIMD variant of k_trunk2: 512 registers hold all 16 frequency accumulators, the LDS the other four waves
 //     would use holds the transformed weights.  MI355X: 473 vs 526 us at 32768 boards, 71 vs 80 us at 4096.  Below 4096
 //     boards k_trunk runs the 16-row form (conv2_wino; same chains, same bits): 21 vs 23 us at 1024 boards.
-//   * 7x6 planes: OFF (AZ_WINOGRAD=1 enables it).  12 tiles per board fill a 16-row tile to 75 %; with 16-row tiles every
-//     32-cycle MFMA needs an operand transformed by the wave itself and a 256-byte weight fragment: the instruction stream,
-//     not the matrix pipe, is the limit -- 103 vs 101 us at 8192 boards even with the weights resident in LDS.  (The 16-row
-//     form on 8x8 planes in the two-waves-per-SIMD kernel: 518 vs 525 us, bound by the weight stream from L2.)
+//   * 7x6 planes (Connect4): ON, in the same 32-row one-wave-per-SIMD form (12 tiles per board, 24 of the 32 rows of the MFMA tile):
+//     100 vs 105.5 us at 8192 boards, 52.9 vs 54.8 at 4096; equal below 4096 boards (16-row form in k_trunk).  The 16-row form in
+//     the two-waves-per-SIMD kernel had not paid (103 vs 101 us: with 16-row tiles every 32-cycle MFMA needs an operand transformed
+//     by the wave itself and a 256-byte weight fragment -- the instruction stream, not the matrix pipe, is the limit).
 //   * 6x6 planes: never (9 tiles per board would leave the MFMA tile 44 % empty).
 // AZ_WINOGRAD=0 switches everything back to the direct form.
 static bool use_wino(int CH, int CW) {
@@ -2510,20 +2510,37 @@ static int solo_t_launch(const float *A, const float *Bw, const float *bias, flo
     return AZ_OK;
 }
 
+// which kernel a dense layer of M rows runs on (one place: launch_gemm dispatches on it, az_net_stage_kernel reports it)
+enum GemmKind { GK_SMALL, GK_SOLO, GK_SOLO_T, GK_TILED };
+static int gemm_solo_env() { static int solo = -2; if (solo == -2) { const char *e = getenv("AZ_GEMM_SOLO"); solo = e ? atoi(e) : -1; } return solo; }
+static GemmKind gemm_kind(int M, int N, int K) {
+    // measured crossover against the tiled GEMM (MI355X): K = 512 up to 128 rows (15 vs 21 us), K = 1024 up to 256 rows (28 vs 40 us)
+    if (M <= (K >= 1024 ? 256 : 128) && K % 32 == 0) return GK_SMALL;  // few rows: latency matters, not throughput
+    // large row counts: the one-wave-per-SIMD kernel (256x256 workgroup tiles), from one tile per CU up.  AZ_GEMM_SOLO=0 / 1 forces.
+    const int solo = gemm_solo_env();
+    const long long tiles = (long long)((M + 255) / 256) * (N / 256);
+    if (solo != 0 && N % 256 == 0 && (solo == 1 || tiles >= 256)) return GK_SOLO;
+    // below that: the same scheme on 128x128 tiles from TWO tiles per CU up (fc1 from 8192 rows, fc2 from 16384; AZ_GEMM_SOLO=2
+    // forces it).  Measured against k_gemm: 76 vs 80 us (fc1, 8192 rows), 137 vs 144 (fc2, 16384); with ONE tile per CU it loses
+    // (4096 rows: 42.6 vs 41.4 us, 64x128 tiles 57 vs 42): a 4096-cycle K tile does not carry its barrier and LDS turnaround
+    // without a partner wave, and k_gemm's two blocks per CU are exactly that partner.
+    if (solo != 0 && solo != 1 && N % 128 == 0) {
+        const long long t128 = (long long)((M + 127) / 128) * (N / 128);
+        if (solo == 2 || (solo < 0 && t128 >= 512)) return GK_SOLO_T;
+    }
+    return GK_TILED;
+}
+
 static int launch_gemm(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
     AZ_REQUIRE(K % 32 == 0, AZ_EINVAL, "GEMM K=%d is not a multiple of 32", K);
-    // measured crossover against the tiled GEMM (MI355X): K = 512 up to 128 rows (15 vs 21 us), K = 1024 up to 256 rows (28 vs 40 us)
-    if (M <= (K >= 1024 ? 256 : 128) && K % 32 == 0) {  // few rows: latency matters, not throughput
-        dim3 grid((unsigned)((N + 63) / 64), (unsigned)M);
-        if (relu) hipLaunchKernelGGL((k_dense_small<true>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
-        else hipLaunchKernelGGL((k_dense_small<false>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
-        return AZ_OK;
-    }
-    {   // large row counts: the one-wave-per-SIMD kernel (256x256 workgroup tiles), from one tile per CU up.  AZ_GEMM_SOLO=0 / 1 forces.
-        static int solo = -2;
-        if (solo == -2) { const char *e = getenv("AZ_GEMM_SOLO"); solo = e ? atoi(e) : -1; }
-        const long long tiles = (long long)((M + 255) / 256) * (N / 256);
-        if (solo != 0 && N % 256 == 0 && (solo == 1 || tiles >= 256)) {
+    switch (gemm_kind(M, N, K)) {
+        case GK_SMALL: {
+            dim3 grid((unsigned)((N + 63) / 64), (unsigned)M);
+            if (relu) hipLaunchKernelGGL((k_dense_small<true>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
+            else hipLaunchKernelGGL((k_dense_small<false>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
+            return AZ_OK;
+        }
+        case GK_SOLO: {
             constexpr int lds = 4 * (2 * 256 * 33 + 2 * 32 * 256);
             static bool attr_set = false;
             if (!attr_set) {
@@ -2536,14 +2553,8 @@ static int launch_gemm(const float *A, const float *Bw, const float *bias, float
             else hipLaunchKernelGGL((k_gemm_solo<false>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
             return AZ_OK;
         }
-        // below that: the same scheme on 128x128 tiles from TWO tiles per CU up (fc1 from 8192 rows, fc2 from 16384; AZ_GEMM_SOLO=2
-        // forces it).  Measured against k_gemm: 76 vs 80 us (fc1, 8192 rows), 137 vs 144 (fc2, 16384); with ONE tile per CU it loses
-        // (4096 rows: 42.6 vs 41.4 us, 64x128 tiles 57 vs 42): a 4096-cycle K tile does not carry its barrier and LDS turnaround
-        // without a partner wave, and k_gemm's two blocks per CU are exactly that partner.
-        if (solo != 0 && solo != 1 && N % 128 == 0) {
-            const long long t128 = (long long)((M + 127) / 128) * (N / 128);
-            if (solo == 2 || (solo < 0 && t128 >= 512)) return solo_t_launch<2, 2>(A, Bw, bias, C, M, N, K, relu, dyn, st);
-        }
+        case GK_SOLO_T: return solo_t_launch<2, 2>(A, Bw, bias, C, M, N, K, relu, dyn, st);
+        default: break;
     }
     // pick the largest tile that still gives every CU two resident blocks (512 blocks on 256 CUs):
     // a block's barrier and LDS-fill phases then overlap the other block's MFMAs
@@ -2779,6 +2790,28 @@ extern "C" int az_net_time_stage(az_net *n, int stage, int B, int iters, void *s
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(in); (void)hipFree(pr); (void)hipFree(va);
     return rc;
+}
+
+// Name of the kernel stage `stage` (0 trunk, 1 fc1, 2 fc2, 3 heads) launches for a batch of B boards: what rocprofv3 lists the
+// launch under (template arguments abbreviated).  bench.py labels its roofline object with it.
+extern "C" int az_net_stage_kernel(const az_net *n, int stage, int B, char *buf, int cap) {
+    AZ_REQUIRE(n && buf && cap > 0 && stage >= 0 && stage <= 3 && B > 0, AZ_EINVAL, "bad arguments");
+    const char *name = "";
+    if (n->game == AZ_TICTACTOE) name = "k_mlp";
+    else if (stage >= 1 && tail_is_fused(n)) name = "k_tail_small";
+    else if (stage == 0) name = (!trunk_v1() && B >= 4096) ? (use_wino(n->CH, n->CW) ? "k_trunk2<Winograd conv2>" : "k_trunk2") : "k_trunk";
+    else if (stage == 3) name = (B <= 128 && n->NH <= 128 && n->F2 % 32 == 0) ? "k_heads_small" : (n->F2 == 512 ? "k_heads2" : "k_heads");
+    else {
+        const int N = stage == 1 ? n->F1 : n->F2, K = stage == 1 ? n->FIN : n->F1;
+        switch (gemm_kind(B, N, K)) {
+            case GK_SMALL: name = "k_dense_small"; break;
+            case GK_SOLO: name = "k_gemm_solo"; break;
+            case GK_SOLO_T: name = "k_gemm_solo_t"; break;
+            default: name = "k_gemm"; break;
+        }
+    }
+    snprintf(buf, (size_t)cap, "%s", name);
+    return AZ_OK;
 }
 
 #ifdef AZ_PROBE

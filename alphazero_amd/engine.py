@@ -161,6 +161,12 @@ class HipNet:
         check(lib().az_net_time_stage(self.h, stage, B, iters, _stream_ptr(), C.byref(ms)))
         return float(ms.value)
 
+    def stage_kernel(self, stage, B):
+        """name of the kernel stage 0..3 launches for B boards (az_net_stage_kernel)"""
+        buf = C.create_string_buffer(64)
+        check(lib().az_net_stage_kernel(self.h, stage, B, buf, 64))
+        return buf.value.decode()
+
     def profile(self, enable=True):
         """bracket every stage launch of the following forwards with HIP events (az_net_profile)"""
         check(lib().az_net_profile(self.h, 1 if enable else 0))
@@ -288,6 +294,16 @@ class SelfPlayEngine:
                                             C.byref(k), C.byref(rn)))
         k = k.value
         return a[:k].copy(), n[:k].copy(), q[:k].copy(), p[:k].copy(), rn.value
+
+    def nodes_used(self, slot=0):
+        n = C.c_int32()
+        check(lib().az_engine_nodes_used(self.h, slot, C.byref(n)))
+        return n.value
+
+    def grow_pools(self, node_capacity):
+        """re-allocates the tree pools with a larger capacity; the trees are kept"""
+        check(lib().az_engine_grow_pools(self.h, node_capacity))
+        self.cfg.node_capacity = node_capacity
 
     def close(self):
         if getattr(self, "h", None):

@@ -50,7 +50,7 @@ class MCT:
             raise ValueError(f"A neural network has been set for the MCT but the evaluation method is {self.eval_method}")
         self._seed = int(np.random.randint(0, 2**31 - 1)) if seed is None else int(seed)
         self._engine = None           # device tree (one engine slot)
-        self._pool_sims = 0           # simulations per search the slot's node pools were sized for (0: compute_time mode)
+        self._engine_board = None     # (game, H, W) the engine was built for
         self._hipnet = None
         self._root_key = None         # (grid bytes, player) of the position the device root stands for
         self._last_board = None
@@ -67,7 +67,6 @@ class MCT:
         self._nn = nn
         self._hipnet = None
         self._engine = None
-        self._pool_sims = 0
         self._root_key = None
 
     def get_stats(self):
@@ -80,11 +79,13 @@ class MCT:
             raise ValueError("MCT.search needs to have either n_sim or compute_time specified.")
         self._sync_device_root(board, n_sim)
         if n_sim is not None:
+            self._ensure_room(n_sim)
             self._engine.search(n_sim)
             self.n_rollouts = n_sim
         else:
             chunk = 1 if self.eval_method == TreeEval.NEURAL else 8
             while time() - start < compute_time:
+                self._ensure_room(chunk)
                 self._engine.search(chunk)
                 self.n_rollouts += chunk
         self.simulation_time = time() - start
@@ -128,9 +129,13 @@ class MCT:
         if neural and self._nn is None:
             raise ValueError("The MCT has no neural network to evaluate positions with.")
         H, W = board.grid.shape
-        if self._engine is not None and n_sim is not None and self._pool_sims and n_sim > self._pool_sims:
-            self._engine.close()  # a longer search than the pools were sized for: new storage, the tree restarts
+        if self._engine is not None and self._engine_board != (board.game, H, W):
+            # the device storage was carried over a reset() from a game on another board (players.py keeps the engine); the
+            # reference's reset() yields a tree usable on any board: rebuild rather than search with the wrong rules
+            self._engine.close()
             self._engine, self._root_key = None, None
+            if self._hipnet is not None and (self._hipnet.H, self._hipnet.W) != (H, W):
+                self._hipnet = None
         if self._engine is None:
             if neural and self._hipnet is None:
                 self._hipnet = self._nn.to_hip(max_batch=16)
@@ -141,11 +146,9 @@ class MCT:
                                           noise_mode=NOISE_PHILOX if noisy else NOISE_OFF,
                                           evaluator=EVAL_NET if neural else EVAL_ROLLOUT,
                                           seed=self._seed, sample_capacity=4 * H * W + 16, max_plies=4 * H * W + 16,
-                                          # one slot.  With a simulation count the pools hold the kept subtree plus one
-                                          # search (<= 65 new nodes per simulation, compacted at every move); searches
-                                          # bounded by wall time get 2 x 64 MiB
-                                          node_capacity=(1 << 21) if n_sim is None else max(1 << 14, min(1 << 21, 160 * n_sim)))
-            self._pool_sims = 0 if n_sim is None else max(n_sim, (1 << 14) // 160)
+                                          # one slot: the pools start small and grow on demand (_ensure_room)
+                                          node_capacity=1 << 14)
+            self._engine_board = (board.game, H, W)
             self._plies = 0
         key = (board.grid.astype(np.int8).tobytes(), int(board.player))
         if key != self._root_key:  # tree restarted from an unexplored state (mcts.py:124-125, 231-233)
@@ -153,3 +156,15 @@ class MCT:
                                    game_ids=np.array([np.random.randint(0, 2**31 - 1)], np.uint32))
             self._root_key = key
         self._last_board = board.clone()
+
+    _MAX_POOL = 1 << 24  # nodes per pool (512 MiB): beyond it the engine reports AZ_ECAPACITY
+
+    def _ensure_room(self, n_sim):
+        """the reference's tree grows without bound while search() is called again and again on one root (mcts.py:226-269);
+        the device pools have a size: before a search of n_sim simulations (each allocates at most one node's children, <= A <= 65
+        nodes) the pools are re-allocated when what is left could run out.  The tree is kept (az_engine_grow_pools)."""
+        eng = self._engine
+        need = eng.nodes_used(0) + 66 * n_sim + 66
+        cap = eng.cfg.node_capacity
+        if need > cap:
+            eng.grow_pools(min(self._MAX_POOL, max(2 * cap, need)))

@@ -54,7 +54,7 @@ class MCTSPlayer(Player):
         old = self.mct
         self.mct = MCT()
         # a reset drops the tree, not the device storage behind it (one engine slot: node pools, sample buffers)
-        self.mct._engine, self.mct._pool_sims = old._engine, old._pool_sims
+        self.mct._engine, self.mct._engine_board = old._engine, old._engine_board
 
     def apply_move(self, move, player=None):
         self.mct.change_root(move)
@@ -92,7 +92,7 @@ class AlphaZeroPlayer(MCTSPlayer):
         self.mct = MCT(eval_method="neural", nn=old.nn, dirichlet_alpha=old.dirichlet_alpha,
                        dirichlet_epsilon=old.dirichlet_epsilon)
         # keep the uploaded weights and the device tree storage: a reset only drops the tree
-        self.mct._hipnet, self.mct._engine, self.mct._pool_sims = old._hipnet, old._engine, old._pool_sims
+        self.mct._hipnet, self.mct._engine, self.mct._engine_board = old._hipnet, old._engine, old._engine_board
         if self.mct._engine is not None:
             self.mct._plies = 0
 

@@ -416,6 +416,12 @@ class AlphaZeroTrainer:
             raise ValueError("distributed training over RCCL needs config.device = 'cuda'")
         self.board = BOARDS_REGISTER[self.game](config=c)
         self.nn = NETWORKS_REGISTER[self.game](config=c)
+        if world > 1:
+            # every rank built its own random initialisation: the job plays and evaluates with rank 0's (self-play shards,
+            # the sharded arena and eval_opponent = "previous" at iteration 0 must not depend on the number of ranks)
+            from .dist import broadcast_state_dict
+            self.nn.to(c.device)
+            broadcast_state_dict(self.nn, src=0)
         self.prev_nn = None
         self.az_player = AlphaZeroPlayer(n_sim=c.simulations, compute_time=c.compute_time, nn=self.nn,
                                          dirichlet_alpha=c.dirichlet_alpha, dirichlet_epsilon=c.dirichlet_epsilon)

@@ -2,7 +2,8 @@
 """Headline benchmark: self-play games/s, Othello 8x8 @ 100 sims/move (BASELINE.json configs[1]).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+Started plainly with N > 1 it launches its own N ranks (one child process per GPU, spawned BEFORE the parent makes any HIP call; the
+parent only relays rank 0's JSON line and fails if any rank fails); under torch.distributed.run (WORLD_SIZE set) it is one rank.
 
 A "step" is one self-play wave: every rank keeps `--games` Othello 8x8 games resident and plays them from the start
 position to the end at 100 MCTS simulations per move through the HIP engine (random-init OthelloNet(n=8) under
@@ -13,12 +14,29 @@ graphs, no event recording); the per-kernel times of the roofline come from one 
 At N = 1 the same JSON line also carries the two single-GPU BASELINE configs at their LITERAL sizes:
   config2 : Othello 8x8, 4096 concurrent games, 100 sims/move           (BASELINE.json configs[1])
   config4 : Connect4 6x7, 8192 concurrent games, 200 sims/move          (BASELINE.json configs[3])
-each with games/s, examples/s and its own roofline object, and `cpu_baseline`: the CPU oracle (C port of the
-reference's self-play loop) timed on the host cores with the protocol of BASELINE.md section 3.
+each with games/s, examples/s and its own roofline object, `config5` (BASELINE.json configs[4]: the trainer loop on Othello 8x8,
+per-phase seconds) and `cpu_baseline`: the CPU oracle (C port of the reference's self-play loop) timed on the host cores with the
+protocol of BASELINE.md section 3.  At N > 1 the line carries `config3` (BASELINE.json configs[2] at its LITERAL size: 32768
+concurrent games sharded N ways, RCCL sample all-gather) and `config5` over all ranks.
+
+How to read `roofline` (every field can be recomputed from profiles/ + the fields beside it):
+  kernel            the kernel with the largest share of the profiled step's network time; fc1 and fc2 are ONE kernel (two launches
+                    per forward), the trunk is k_trunk2 (+ the few small-batch launches of k_trunk at the end of a wave)
+  achieved          flops_per_board x boards_evaluated / kernel_ms_total                     [TFLOP/s]
+                    dense layers: flops_per_board = 2 (FIN F1 + F1 F2) algorithmic = executed;
+                    trunk: the FLOPs the kernel ISSUES (conv2 in the Winograd form issues fewer multiplications than the direct
+                    form) -- the direct-form figure is in frac_algorithmic_direct_form
+  frac              achieved / peak (157.3 TFLOP/s, f32-input MFMA): how busy the matrix pipe is, never above 1
+  avg_launch_ms     kernel_ms_total / launches: what rocprofv3 --stats lists as the kernel's average duration
+  forward_frac      all four stages: algorithmic FLOPs of a forward x boards / network time / peak
+  end_to_end_frac   boards the TIMED region evaluated x algorithmic FLOPs of a forward / timed seconds / peak (per GPU)
+  traffic, mfma_busy  PMC figures of one full-batch launch (profiles/traffic.json, mfma_counters.json), used only when the files'
+                    `csrc_sha` equals the hash of the sources this build was made from (alphazero_amd._lib.csrc_tree_hash), else null
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -29,11 +47,19 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver (before any HIP call)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+
+torch = dist = None  # imported by _imports(): the self-launching parent never loads torch, let alone HIP
+
+
+def _imports():
+    global torch, dist
+    import torch as _t
+    import torch.distributed as _d
+    torch, dist = _t, _d
+
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
-PROF_NAMES = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads"]
+SLOTS = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads", "k_trunk"]  # az_net_profile_read's five counters
 # the Python reference and the C oracle on ONE core of the build container (Xeon @ 2.10 GHz, 8 vCPU): BASELINE.md section 2
 # (8.38 s per Othello 8x8 game at 100 sims) and `python oracle/selfplay_worker.py` there (4 games: 6.33 +- 0.73 s per game)
 REF_S_PER_GAME_BUILD_CONTAINER = 8.38
@@ -48,9 +74,8 @@ def stage_flops(CH, CW, F1, F2, A):
 
 
 def executed_conv_flops(CH, CW):
-    """FLOPs the trunk kernel EXECUTES per board on the matrix cores: conv2 of 8x8 and 7x6 planes runs in the Winograd F(2x2,3x3)
-    form (tiles x 16 frequencies x 32 x 32 MACs instead of positions x 9 x 32 x 32; AZ_WINOGRAD=0 switches it off) -- the SURVEY's
-    algorithmic figure stays the numerator of `frac`, this one is reported beside it"""
+    """FLOPs the trunk kernel ISSUES per board on the matrix cores: conv2 of 8x8 and 7x6 planes runs in the Winograd F(2x2,3x3)
+    form (tiles x 16 frequencies x 32 x 32 MACs instead of positions x 9 x 32 x 32; AZ_WINOGRAD=0 switches it off)"""
     p1, p3, p4 = CH * CW, (CH - 2) * (CW - 2), (CH - 4) * (CW - 4)
     wino = (CH, CW) in ((8, 8), (7, 6)) and os.environ.get("AZ_WINOGRAD", "") != "0"
     conv2 = ((CH + 1) // 2) * ((CW + 1) // 2) * 16 * 32 * 32 if wino else p1 * 9 * 32 * 32
@@ -61,6 +86,50 @@ def algorithmic_bytes(CH, CW, F1, F2, A):
     """algorithmic HBM bytes per board of the four network stages (inputs + outputs; weights stay cache resident)"""
     fin = 32 * (CH - 4) * (CW - 4)
     return [4 * (CH * CW + fin), 4 * (fin + F1), 4 * (F1 + F2), 4 * (F2 + A + 1)]
+
+
+def stamped(name):
+    """profiles/<name> if it was measured on the sources this build was made from, else None (+ why)"""
+    from alphazero_amd import _lib
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, "no such file"
+    d = json.load(open(path))
+    have, want = d.get("csrc_sha"), _lib.csrc_tree_hash()
+    if have != want:
+        return None, f"profiles/{name} was measured on csrc tree {have}, this build is {want}: dropped"
+    return d, f"profiles/{name}, csrc tree {have}"
+
+
+# ------------------------------------------------------------------------------------------------ self-launch
+def self_launch(n):
+    """`python bench.py --gpus N` started plainly: N fresh child processes, one per GPU, each with the environment
+    torch.distributed.run would give it.  The parent has made no HIP call (torch is not even imported) and makes none: it waits,
+    relays rank 0's stdout (the JSON line) and exits non-zero as soon as any rank fails (the others are then terminated)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AZ_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))  # rank 0 inherits stdout: its JSON line is ours
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive:
+                    procs[q].terminate()  # exactly the processes started above
+        time.sleep(0.2)
+    return rc
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -76,7 +145,7 @@ def cpu_model():
 
 def cpu_baseline(state_dict, n_sim=100, games_per_proc=3):
     """BASELINE.md section 3 on this box's host cores, with the CPU oracle (the checker; C port of the reference's loop):
-    one process, then one process per core (<= 16), >= 3 games each, every game timed (SelfPlayTimer idiom,
+    one process, then one process per core of the lease's CPU share, >= 3 games each, every game timed (SelfPlayTimer idiom,
     timers.py:53-76); then the Arena path (AlphaZeroPlayer @100 vs rollout MCTSPlayer @100, 2 rounds, arena.py:119-185).
     Runs BEFORE this process touches the GPU: the workers are plain child processes that never see HIP."""
     from oracle import oracle as O
@@ -85,7 +154,12 @@ def cpu_baseline(state_dict, n_sim=100, games_per_proc=3):
     t_all = time.perf_counter()
     one = W.play(weights, games_per_proc, n_sim, 0)
     s1 = np.array(one["seconds_per_game"])
-    nproc = max(1, min(os.cpu_count() or 1, 16))
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    # a one-GPU lease of the pool owns 16 cores of the host (its 256 hardware threads are shared by 8 leases)
+    nproc = max(1, min(usable, int(os.environ.get("AZ_BENCH_CPU_PROCS", "16"))))
     many = None
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "w.npz")
@@ -100,7 +174,8 @@ def cpu_baseline(state_dict, n_sim=100, games_per_proc=3):
             per = np.concatenate([json.loads(o.strip().splitlines()[-1])["seconds_per_game"] for o in outs])
             plies = sum(json.loads(o.strip().splitlines()[-1])["plies"] for o in outs)
             many = {"processes": nproc, "games": int(len(per)), "wall_s": wall, "games_per_sec": len(per) / wall, "examples_per_sec": plies / wall,
-                    "s_per_game_mean": float(per.mean()), "s_per_game_std": float(per.std())}
+                    "s_per_game_mean": float(per.mean()), "s_per_game_std": float(per.std()),
+                    "note": "one process per core of this lease's CPU share (16 of the host's hardware threads), not of the whole host"}
     net = O.ConvNet(O.OTHELLO, 8, 8, weights)
     t0 = time.perf_counter()
     moves, winners, _, _ = O.arena_games((O.OTHELLO, 8, 8), ("conv", net), n_sim, "mcts", n_sim, seed=0, n_rounds=2)
@@ -108,10 +183,10 @@ def cpu_baseline(state_dict, n_sim=100, games_per_proc=3):
     return {"value": 1.0 / float(s1.mean()), "unit": "games/s", "cores": 1, "kind": "port",
             "sample": f"{games_per_proc} full Othello 8x8 self-play games at {n_sim} sims/move ({one['plies']} plies, {one['net_evals']} net evals) "
                       f"on 1 host core, oracle/liboracle.so; then {nproc} processes x {games_per_proc} games; then 2 Arena rounds",
-            "cpu_model": cpu_model(), "nproc": os.cpu_count(),
+            "cpu_model": cpu_model(), "host_hardware_threads": os.cpu_count(), "usable_cores": usable,
             "one_process": {"games": games_per_proc, "s_per_game_mean": float(s1.mean()), "s_per_game_std": float(s1.std()),
                             "games_per_sec": 1.0 / float(s1.mean()), "examples_per_sec": one["plies"] / float(s1.sum())},
-            "all_cores": many,
+            f"{nproc}_processes": many,
             "arena": {"rounds": 2, "player1": f"AlphaZeroPlayer({n_sim} sims)", "player2": f"MCTSPlayer(rollout, {n_sim} sims)",
                       "seconds": t_arena, "s_per_game": t_arena / 2, "plies": [len(m) for m in moves], "winners": winners},
             "reference_python": {"s_per_game": REF_S_PER_GAME_BUILD_CONTAINER, "games_per_sec": 1.0 / REF_S_PER_GAME_BUILD_CONTAINER,
@@ -150,12 +225,15 @@ class Workload:
                                     noise_mode=E.NOISE_PHILOX, seed=seed, max_plies=plies,
                                     sample_capacity=self.per_step * (72 if game == "othello" else 43))
 
+    def forward_flops(self):
+        return sum(stage_flops(*self.geom))
+
     def wave(self, first_game_id):
         """one step on this rank: per_step games to the end; returns (samples dict of device views, engine stats)"""
         self.eng.run(self.per_step, first_game_id=first_game_id)
         return self.eng.samples(copy=False), self.eng.stats()
 
-    def profiled_wave(self, first_game_id):
+    def profiled_wave(self, first_game_id, timed_evals=None, timed_seconds=None):
         """one more step with HIP events around every network kernel launch (az_net_profile; kernel-by-kernel launches
         instead of graph replays).  -> roofline object of the dominant kernel + the step's time split"""
         self.hnet.profile(True)
@@ -168,59 +246,71 @@ class Workload:
         ov = self.hnet.profile_overhead_ms()  # an event-to-event interval costs this much with no kernel in it
         self.hnet.profile(False)
         fl, by = stage_flops(*self.geom), algorithmic_bytes(*self.geom)
-        if self.game == "connect4":  # fc1 + fc2 + heads are one fused launch, booked in the fc1 slot
-            fl = [fl[0], fl[1] + fl[2] + fl[3], 0, 0]
+        fused_tail = self.game == "connect4"  # fc1 + fc2 + heads are one fused launch (k_tail_small), booked in the fc1 slot
         evals = st["net_evals"]
-        raw_ms = [prof[k][0] for k in PROF_NAMES]
-        raw_ms[0] += prof["k_trunk"][0]  # small-batch launches of the one-board-per-wave trunk kernel
-        launches = [prof[k][1] for k in PROF_NAMES]
-        launches[0] += prof["k_trunk"][1]
-        tot_ms = [max(raw_ms[i] - ov * launches[i], 1e-9) for i in range(4)]  # kernel time: what rocprofv3 reports per dispatch
-        dom = int(np.argmax(tot_ms))
-        ach = fl[dom] * evals / (tot_ms[dom] * 1e-3) / 1e12
+        raw = {k: prof[k][0] for k in SLOTS}
+        cnt = {k: prof[k][1] for k in SLOTS}
+        ms = {k: max(raw[k] - ov * cnt[k], 0.0) for k in SLOTS}  # kernel time: what rocprofv3 reports per dispatch
+        exe, wino = executed_conv_flops(*self.geom[:2])
+        # the kernels of a forward.  fc1 and fc2 are two launches of ONE kernel; the trunk's few small-batch launches (k_trunk, end of a
+        # wave) are booked with k_trunk2: their boards are in `evals` too
+        kern = {
+            "trunk": {"name": self.hnet.stage_kernel(0, self.G), "ms": ms["k_trunk2"] + ms["k_trunk"], "launches": cnt["k_trunk2"],
+                      "own_ms": ms["k_trunk2"], "flops": exe, "flops_algorithmic": fl[0], "bytes": by[0], "pmc": ["k_trunk"]},
+            "dense": {"name": self.hnet.stage_kernel(1, self.G), "ms": ms["k_gemm fc1"] + ms["k_gemm fc2"], "launches": cnt["k_gemm fc1"] + cnt["k_gemm fc2"],
+                      "own_ms": ms["k_gemm fc1"] + ms["k_gemm fc2"], "flops": fl[1] + fl[2] + (fl[3] if fused_tail else 0),
+                      "flops_algorithmic": fl[1] + fl[2] + (fl[3] if fused_tail else 0), "bytes": by[1] + by[2], "pmc": ["k_gemm_fc1", "k_gemm_fc2"] if not fused_tail else ["k_tail"]},
+            "heads": {"name": self.hnet.stage_kernel(3, self.G), "ms": ms["k_heads"], "launches": cnt["k_heads"], "own_ms": ms["k_heads"],
+                      "flops": fl[3], "flops_algorithmic": fl[3], "bytes": by[3], "pmc": ["k_heads"]},
+        }
+        if not fused_tail and self.hnet.stage_kernel(2, self.G) != kern["dense"]["name"]:
+            kern["dense"]["name"] += " (fc1) / " + self.hnet.stage_kernel(2, self.G) + " (fc2)"
+        net_ms = sum(k["ms"] for k in kern.values())
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        K = kern[dom]
+        ach = K["flops"] * evals / (K["ms"] * 1e-3) / 1e12
         key = f"{self.game}_{self.G}"
-        traffic, counters = None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per full-batch launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tfile):
-            t = json.load(open(tfile)).get(key)
-            if t:
-                traffic = t.get(["k_trunk", "k_gemm_fc1", "k_gemm_fc2", "k_heads"][dom])
-        cfile = os.path.join(ROOT, "profiles", "mfma_counters.json")  # SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES passes
-        if os.path.exists(cfile):
-            counters = json.load(open(cfile)).get(key)
+        tfile, twhy = stamped("traffic.json")  # HBM bytes per full-batch launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        cfile, cwhy = stamped("mfma_counters.json")  # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE passes
+        traffic = None
+        if tfile and tfile.get(key) and all(p in tfile[key] for p in K["pmc"]):
+            traffic = sum(tfile[key][p] for p in K["pmc"])
+        busy = None
+        if cfile and cfile.get(key):
+            b = [cfile[key].get(p, {}).get("mfma_busy_frac") for p in K["pmc"]]
+            busy = float(np.mean(b)) if all(x is not None for x in b) else None
         full = [self.hnet.time_stage(s, self.G, iters=20) for s in range(4)]
-        net_ms = sum(tot_ms)
-        roof = {"bound": "mfma", "kernel": PROF_NAMES[dom] + (" (+k_trunk at small batches)" if dom == 0 and prof["k_trunk"][1] else ""),
+        roof = {"bound": "mfma", "kernel": K["name"] + (" (fc1 + fc2: two launches per forward)" if dom == "dense" and not fused_tail else ""),
                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "traffic": traffic,
-                "traffic_is_for": f"one launch at the full batch of {self.G} boards (tools/prof_net.py under rocprofv3 --pmc); algorithmic bytes of that launch: {self.G * by[dom]}",
-                "mfma_busy": (counters or {}).get(["k_trunk", "k_gemm_fc1", "k_gemm_fc2", "k_heads"][dom]),
-                # the kernel's own launches (what rocprofv3 lists under its name); for the trunk, `achieved` also covers the few
-                # small-batch launches of k_trunk at the end of a wave (their boards and their time)
-                "launches": prof[PROF_NAMES[dom]][1],
-                "avg_launch_ms": max(prof[PROF_NAMES[dom]][0] - ov * prof[PROF_NAMES[dom]][1], 0.0) / max(1, prof[PROF_NAMES[dom]][1]),
-                "avg_launch_ms_with_event_overhead": prof[PROF_NAMES[dom]][0] / max(1, prof[PROF_NAMES[dom]][1]), "event_overhead_ms_per_interval": ov,
-                "small_batch_trunk_launches": prof["k_trunk"][1] if dom == 0 else 0,
-                "achieved_uncorrected": fl[dom] * evals / (raw_ms[dom] * 1e-3) / 1e12,
-                "avg_boards_per_launch": evals / max(1, launches[dom]),
-                "algorithmic_flops_per_board": fl[dom], "boards_evaluated": evals,
-                **({"executed_flops_per_board": executed_conv_flops(*self.geom[:2])[0],
-                    "achieved_executed": executed_conv_flops(*self.geom[:2])[0] * evals / (tot_ms[0] * 1e-3) / 1e12,
-                    "frac_executed": executed_conv_flops(*self.geom[:2])[0] * evals / (tot_ms[0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                    "conv2_form": "Winograd F(2x2,3x3): `frac` counts the SURVEY's algorithmic FLOPs of the direct form, `frac_executed` "
-                                  "the multiplications the kernel issues" if executed_conv_flops(*self.geom[:2])[1] else "direct"} if dom == 0 else {}),
+                "flops_per_board": K["flops"], "boards_evaluated": evals, "kernel_ms_total": K["ms"], "launches": K["launches"],
+                "avg_launch_ms": K["own_ms"] / max(1, K["launches"]), "avg_boards_per_launch": evals / max(1, cnt["k_trunk2"] + cnt["k_trunk"]),
+                "share_of_network_time": K["ms"] / net_ms,
+                "traffic": traffic, "traffic_algorithmic": self.G * K["bytes"], "traffic_source": twhy,
+                "traffic_is_for": f"one launch of every stage of the kernel at the full batch of {self.G} boards (tools/prof_net.py under rocprofv3 --pmc)",
+                "mfma_busy": busy, "mfma_busy_source": cwhy,
+                "event_overhead_ms_per_interval": ov,
                 "measured_on": "one separately profiled step after the timed region: HIP events on the engine's stream around every launch, "
                                "minus the calibrated cost of an empty event interval per launch",
                 "profiled_step_ms": 1e3 * dt,
-                "profiled_step_kernel_ms": {k: prof[k][0] for k in prof}, "profiled_step_launches": {k: prof[k][1] for k in prof},
-                "stage_tflops": {PROF_NAMES[i]: (fl[i] * evals / (tot_ms[i] * 1e-3) / 1e12 if tot_ms[i] > 0.05 * raw_ms[i] else None) for i in range(4)},
-                "full_batch_launch_ms": dict(zip(PROF_NAMES, full)),
-                "full_batch_tflops": {PROF_NAMES[i]: fl[i] * self.G / (full[i] * 1e-3) / 1e12 for i in range(4)},
-                "forward_tflops": sum(fl) * evals / (net_ms * 1e-3) / 1e12,
-                "network_share_of_profiled_step": sum(raw_ms) / (1e3 * dt),
-                "tree_and_host_share_of_profiled_step": 1.0 - sum(raw_ms) / (1e3 * dt)}
-        if self.game == "connect4":
-            roof["note"] = "Connect4Net: fc1 + fc2 + heads run as ONE fused launch (k_tail_small), booked under 'k_gemm fc1'"
+                "kernels": {k: {"name": v["name"], "ms": v["ms"], "launches": v["launches"], "flops_per_board": v["flops"],
+                                "tflops": v["flops"] * evals / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None,
+                                "frac": v["flops"] * evals / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if v["ms"] > 0 else None,
+                                "share_of_network_time": v["ms"] / net_ms} for k, v in kern.items() if v["launches"]},
+                "profiled_step_kernel_ms_raw": raw, "profiled_step_launches": cnt,
+                "full_batch_launch_ms": dict(zip(["trunk", "fc1", "fc2", "heads"], full)),
+                "forward_flops_per_board": sum(fl),
+                "forward_frac": sum(fl) * evals / (net_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "network_share_of_profiled_step": sum(raw.values()) / (1e3 * dt)}
+        if dom == "trunk":
+            roof["conv2_form"] = "Winograd F(2x2,3x3)" if wino else "direct"
+            roof["small_batch_trunk_launches"] = cnt["k_trunk"]
+            roof["frac_algorithmic_direct_form"] = fl[0] * evals / (K["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+            roof["flops_per_board_direct_form"] = fl[0]
+        if timed_evals is not None and timed_seconds:
+            roof["end_to_end_frac"] = timed_evals * sum(fl) / timed_seconds / 1e12 / PEAK_F32_MFMA_TFLOPS
+            roof["end_to_end_tflops"] = timed_evals * sum(fl) / timed_seconds / 1e12
+        if fused_tail:
+            roof["note"] = "Connect4Net: fc1 + fc2 + heads run as ONE fused launch (k_tail_small), booked under 'dense'"
         return roof
 
     def close(self):
@@ -250,8 +340,166 @@ def run_single(name, game, G, sims, steps, warmup, waves):
            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "plies_per_game": n_samples / games,
            "net_evals_per_step": evals / steps, "lockstep_iters_last_step": st["lockstep_iters"], "graph_replays": st["graph_replays"],
            "max_tree_nodes_per_game": st["max_nodes_used"], "dtype": "f32"}
-    out["roofline"] = w.profiled_wave((warmup + steps) * G)
+    out["roofline"] = w.profiled_wave((warmup + steps) * G, timed_evals=evals, timed_seconds=dt)
     w.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ distributed helpers
+class Job:
+    """the torch.distributed job this rank belongs to (world 1: no group)"""
+
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # AZ_BENCH_BACKEND=gloo + AZ_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 control flow on a one-GPU box (never a fallback:
+        # with the default backend a failing RCCL init is an error)
+        self.backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
+        if os.environ.get("AZ_BENCH_ONE_DEVICE") == "1":
+            self.local_rank = 0
+        self.dev = "cuda" if self.backend == "nccl" else "cpu"
+
+    def init(self):
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(self.backend)
+
+    def sync(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        t = torch.tensor([x], dtype=torch.float64, device=self.dev)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_rows(self, values):
+        """[world, len(values)] float64 array of every rank's values"""
+        t = torch.tensor(values, dtype=torch.float64, device=self.dev)
+        if self.world == 1:
+            return t.view(1, -1).cpu().numpy()
+        out = torch.zeros(self.world * len(values), dtype=torch.float64, device=self.dev)  # flat: the one layout every backend concatenates alike
+        dist.all_gather_into_tensor(out, t)
+        return out.view(self.world, -1).cpu().numpy()
+
+
+def timed_waves(job, w, steps, warmup):
+    """`steps` self-play waves of w on every rank + (N > 1) the all-gather of the samples, bracketed by barrier + synchronize on
+    both sides.  -> dict with the max-over-ranks time and every rank's own time / gather time"""
+    from alphazero_amd.dist import all_gather_samples, rank_game_range
+    G = w.per_step
+    gather_s = [0.0]
+
+    def step(wave):
+        first, _ = rank_game_range(job.rank, job.world, G, wave)
+        smp, st = w.wave(first)
+        if job.world > 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            smp = all_gather_samples({k: smp[k] for k in ("state", "pi", "z", "meta")})
+            torch.cuda.synchronize()
+            gather_s[0] += time.perf_counter() - t0
+        return smp["z"].shape[0], st["net_evals"]
+
+    for i in range(warmup):
+        step(i)
+    gather_s[0] = 0.0
+    job.sync()
+    t0 = time.perf_counter()
+    samples, evals = 0, 0
+    for k in range(steps):
+        s, e = step(warmup + k)
+        samples += s  # after the all-gather every rank holds all ranks' samples
+        evals += e
+    t_local = time.perf_counter() - t0  # this rank's own time, before it waits for the others
+    job.sync()
+    dt = job.max_over_ranks(time.perf_counter() - t0)
+    per_rank = job.gather_rows([t_local, gather_s[0], float(evals)])
+    return {"dt": dt, "samples": samples, "evals_rank0": evals, "evals_all": float(per_rank[:, 2].sum()),
+            "per_rank_ms_per_step": [1e3 * float(x) / steps for x in per_rank[:, 0]],
+            "per_rank_gather_ms_per_step": [1e3 * float(x) / steps for x in per_rank[:, 1]]}
+
+
+def run_config3(job, total_games, sims, steps, warmup):
+    """BASELINE.json configs[2] at its literal size: `total_games` (32768) concurrent Othello games sharded over the N ranks
+    (4096 per GPU at N = 8), RCCL all-gather of the samples after every wave"""
+    per = total_games // job.world
+    w = Workload("config3", "othello", per, sims)
+    r = timed_waves(job, w, steps, warmup)
+    games = steps * per * job.world
+    out = {"workload": f"Othello 8x8, {total_games} concurrent self-play games sharded {job.world} ways ({per} per GPU), {sims} sims/move, "
+                       f"RCCL all-gather of the samples after every wave", "concurrent_games_per_gpu": per, "n_gpus": job.world,
+           "value": games / r["dt"], "unit": "games/s", "examples_per_sec": r["samples"] / r["dt"], "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * r["dt"] / steps, "per_rank_ms_per_step": r["per_rank_ms_per_step"],
+           "per_rank_gather_ms_per_step": r["per_rank_gather_ms_per_step"], "dtype": "f32",
+           "end_to_end_frac_per_gpu": r["evals_all"] / job.world * w.forward_flops() / r["dt"] / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    w.close()
+    return out
+
+
+def run_config5(job, episodes, sims, eval_episodes=64, variants=None):
+    """BASELINE.json configs[4]: AlphaZeroTrainer's loop on Othello 8x8 (trainer.py:475-572: self-play -> optimize_network ->
+    update_network -> evaluate against the PREVIOUS network), two iterations per variant with per-phase wall times.  At N > 1 the
+    episodes and the evaluation rounds are sharded over the ranks, rank 0 runs the SGD, the weights are broadcast."""
+    from alphazero_amd import base
+    from alphazero_amd.games.othello import OthelloConfig
+    from alphazero_amd.trainer import AlphaZeroTrainer
+    if variants is None:
+        # the reference's hyper-parameters are batch_size 64, 10 epochs (games/othello.py:34-35); ONE epoch is run here (stated), on a
+        # smaller episode count for the batch-64 variant so that both variants do a comparable number of SGD steps
+        variants = [("reference_batch_64", dict(episodes=max(64, episodes // 8), batch_size=64, epochs=1)),
+                    ("batch_512", dict(episodes=episodes, batch_size=512, epochs=1))]
+    base.DEFAULT_MODELS_PATH = tempfile.mkdtemp() + "/"
+    out = {"workload": f"Othello 8x8 trainer loop: self-play ({sims} sims/move) + symmetry augmentation + SGD (momentum 0.9, weight decay 1e-4, "
+                       f"ExponentialLR 0.9) + weight hand-off + {eval_episodes} arena games against the previous network", "n_gpus": job.world,
+           "note": "iteration 0 carries one-off costs (engine creation, graph capture, MIOpen's algorithm search when the stock PyTorch step runs); "
+                   "iteration 1 is the steady state", "variants": {}}
+    for name, v in variants:
+        torch.manual_seed(0)
+        tr = AlphaZeroTrainer(verbose=False, engine_slots=min(v["episodes"], 32768), seed=0, materialize_memory=False)
+        tr.game = "othello"
+        tr.config = OthelloConfig(board_size=8, simulations=sims, episodes=v["episodes"], epochs=v["epochs"], batch_size=v["batch_size"], iterations=2,
+                                  device="cuda", eval_opponent="previous", eval_episodes=eval_episodes, do_eval=True, save=False, save_checkpoints=False)
+        tr.setup()
+        its = []
+        for it in range(2):
+            phases = {}
+
+            def timed(label, fn):
+                job.sync()
+                t0 = time.perf_counter()
+                fn()
+                job.sync()
+                phases[label] = job.max_over_ranks(time.perf_counter() - t0)
+
+            timed("self_play_and_augmentation", lambda: tr.self_play(it))
+            n = int(tr.device_memory["z"].shape[0])
+            timed("optimize_network", lambda: tr.optimize_network(it))
+            timed("update_network", lambda: tr.update_network(it))
+            timed("evaluate", lambda: tr.evaluate(it))
+            steps = v["epochs"] * (n // v["batch_size"])
+            res = tr.eval_results["results"].get(it) if job.rank == 0 else None
+            its.append({"iteration": it, "samples_with_twins": n, "sgd_steps": steps, "seconds": phases, "iteration_seconds": sum(phases.values()),
+                        "sgd_ms_per_step": 1e3 * phases["optimize_network"] / max(1, steps),
+                        "sgd_share": phases["optimize_network"] / sum(phases.values()),
+                        "last_losses": ({k: tr.loss_values[it][v["epochs"] - 1][k][-1] for k in ("pi", "v")} if job.rank == 0 else None),
+                        "eval_results": res})
+        out["variants"][name] = {**v, "sgd_step": getattr(tr, "sgd_backend", "torch"), "iterations": its,
+                                 "games_per_sec_whole_loop": v["episodes"] / its[1]["iteration_seconds"],
+                                 "examples_per_sec_whole_loop": its[1]["samples_with_twins"] / its[1]["iteration_seconds"]}
+        if tr._engine is not None:
+            tr._engine.close()
+        if tr._hipnet is not None:
+            tr._hipnet.close()
+        del tr
+        torch.cuda.empty_cache()
     return out
 
 
@@ -263,84 +511,37 @@ def main():
     ap.add_argument("--games", type=int, default=32768, help="concurrent games (engine slots) per GPU of the headline run")
     ap.add_argument("--waves", type=int, default=1, help="games per step per GPU = waves x games (finished slots are refilled)")
     ap.add_argument("--sims", type=int, default=100)
+    ap.add_argument("--config3-total", type=int, default=32768, help="N > 1: concurrent games of config3, sharded over the ranks")
+    ap.add_argument("--config5-episodes", type=int, default=4096, help="episodes per iteration of the config5 trainer loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-literal-configs", action="store_true", help="skip the config2 / config4 objects (N = 1 only)")
+    ap.add_argument("--no-literal-configs", action="store_true", help="skip the config2 / config3 / config4 / config5 objects")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))  # before torch is imported: the parent never touches HIP
+
+    _imports()
+    job = Job()
+    if job.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={job.world}")
 
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:  # before HIP is initialised: the worker processes are forked from a GPU-free parent
+    if job.world == 1 and not args.no_cpu_baseline:  # before HIP is initialised: the worker processes are forked from a GPU-free parent
         from alphazero_amd.games.othello import OthelloNet
         torch.manual_seed(0)
         cpu = cpu_baseline(OthelloNet(n=8).eval().state_dict())
 
-    # AZ_BENCH_BACKEND=gloo + AZ_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 control flow on a one-GPU box
-    backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
-    if os.environ.get("AZ_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    from alphazero_amd.dist import all_gather_samples, rank_game_range
+    job.init()
+    rank, world = job.rank, job.world
 
     w = Workload("headline", "othello", args.games, args.sims, waves=args.waves)
     G = w.per_step
-    gather_s = [0.0]
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def step(wave):
-        first, cnt = rank_game_range(rank, world, G, wave)
-        smp, st = w.wave(first)
-        if world > 1:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            smp = all_gather_samples({k: smp[k] for k in ("state", "pi", "z", "meta")})
-            torch.cuda.synchronize()
-            gather_s[0] += time.perf_counter() - t0
-        return smp["z"].shape[0], st["net_evals"]
-
-    for i in range(args.warmup):
-        step(i)
-    gather_s[0] = 0.0
-    sync()
-    t0 = time.perf_counter()
-    n_samples_total, evals_total = 0, 0
-    for k in range(args.steps):
-        s, e = step(args.warmup + k)
-        n_samples_total += s
-        evals_total += e
-    t_local = time.perf_counter() - t0  # this rank's own time, before it waits for the others
-    sync()
-    dt = time.perf_counter() - t0
-    dev = "cuda" if backend == "nccl" else "cpu"
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    per_rank = torch.tensor([t_local, gather_s[0]], dtype=torch.float64, device=dev)
-    per_rank_all = per_rank.clone().view(1, 2)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per_rank_all = torch.zeros(world * 2, dtype=torch.float64, device=dev)  # flat: the one layout every backend concatenates alike
-        dist.all_gather_into_tensor(per_rank_all, per_rank)
-    dt = float(t.item())
-    per_rank_all = per_rank_all.view(-1, 2).cpu().numpy()
+    r = timed_waves(job, w, args.steps, args.warmup)
+    dt, samples = r["dt"], r["samples"]
     st = w.eng.stats()
 
     if rank == 0:
         games = args.steps * G * world
-        samples = n_samples_total  # after the all-gather every rank holds all ranks' samples
         out = {
             "metric": "self-play games/sec (whole node), Othello 8x8 @100 sims/move", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -351,33 +552,44 @@ def main():
             "plies_per_game": samples / games, "net_evals_last_step": st["net_evals"], "lockstep_iters_last_step": st["lockstep_iters"],
             "graph_replays": st["graph_replays"], "max_tree_nodes_per_game": st["max_nodes_used"],
             # diagnosis of a scaling run: every rank's own step time (before waiting for the others) and its share spent in the RCCL gather
-            "per_rank_ms_per_step": [1e3 * float(x) / args.steps for x in per_rank_all[:, 0]],
-            "per_rank_gather_ms_per_step": [1e3 * float(x) / args.steps for x in per_rank_all[:, 1]],
+            "per_rank_ms_per_step": r["per_rank_ms_per_step"], "per_rank_gather_ms_per_step": r["per_rank_gather_ms_per_step"],
         }
     if world > 1:
         dist.barrier()
     # the roofline's per-kernel times: one extra step, profiled, outside the timed region (rank 0; the others idle at the barrier)
-    roof = w.profiled_wave((args.warmup + args.steps) * G * world + rank * G) if rank == 0 else None
+    roof = w.profiled_wave((args.warmup + args.steps) * G * world + rank * G, timed_evals=r["evals_all"] / world, timed_seconds=dt) if rank == 0 else None
     w.close()
+    if world > 1:
+        dist.barrier()
+    config3 = config5 = None
+    if not args.no_literal_configs:
+        if world > 1:
+            config3 = run_config3(job, args.config3_total, args.sims, steps=2, warmup=1)
+        config5 = run_config5(job, args.config5_episodes, args.sims)
     if rank == 0:
         out["roofline"] = roof
         sims_per_gpu = samples * args.sims / dt / world
         tree = {"algorithmic_bytes_per_sim": 919, "achieved": sims_per_gpu * 919 / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": sims_per_gpu * 919 / 8e12, "note": "per GPU, whole path: the tree kernels are a few % of a step, the path is bound by the network's MFMA work"}
-        kfile = os.path.join(ROOT, "profiles", "kstep_counters.json")  # k_step<true,true>: duration + FETCH_SIZE / WRITE_SIZE passes (tools/refresh_profiles.sh)
-        if os.path.exists(kfile):
-            tree["k_step"] = json.load(open(kfile)).get(f"othello_{w.G}")
+        kfile, kwhy = stamped("kstep_counters.json")  # k_step<true,true>: duration + FETCH_SIZE / WRITE_SIZE passes (tools/refresh_profiles.sh)
+        tree["k_step"] = kfile.get(f"othello_{w.G}") if kfile else None
+        tree["k_step_source"] = kwhy
         out["tree_hbm"] = tree
+        if config3 is not None:
+            out["config3"] = config3
         if world == 1 and not args.no_literal_configs:
             # Othello games all last 60-65 plies: one synchronised wave per step keeps 92 % of the leaf rows filled (the rest are
             # terminal leaves, which need no evaluation).  Connect4 games last 18-42 plies: finished slots are refilled and a
             # step plays 8 x 8192 games, so that the drain at the end of a step (its length is one game) is amortised
             out["config2"] = run_single("config2", "othello", 4096, 100, steps=3, warmup=1, waves=1)
             out["config4"] = run_single("config4", "connect4", 8192, 200, steps=2, warmup=1, waves=8)
+        if config5 is not None:
+            out["config5"] = config5
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -98,6 +98,8 @@ int64_t az_net_flops_per_board(const az_net *net);
 /* times `iters` back-to-back launches of one forward stage with HIP events on `stream`;
  * stage: 0 conv trunk, 1 fc1, 2 fc2, 3 heads, -1 whole forward.  *ms_per_launch out. */
 int az_net_time_stage(az_net *net, int stage, int B, int iters, void *stream, float *ms_per_launch);
+/* name of the kernel that stage (0..3) launches for a batch of B boards, as rocprofv3 lists it (template arguments abbreviated) */
+int az_net_stage_kernel(const az_net *net, int stage, int B, char *buf, int cap);
 /* Live measurement (the idiom of timers.py:53-76 applied per kernel): while enabled, every forward brackets its stage
  * launches with HIP events on its own stream.  ms_total[5] / launches[5]: k_trunk2, k_gemm fc1, k_gemm fc2, k_heads,
  * k_trunk (one board per wave, small batches). */
@@ -165,6 +167,11 @@ int az_engine_play(az_engine *e, const int32_t *h_actions, int32_t n, int32_t *h
 /* root statistics of one slot to HOST arrays (capacity AZ_MAX 65): actions, N, Q, P */
 int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_actions, int32_t *h_N, double *h_Q,
                             double *h_P, int32_t *count, int32_t *root_N);
+/* The reference's tree (mcts.py:8-47 Node objects) grows without bound while MCT.search is called again and again on one root;
+ * the engine's pools have a fixed size: nodes the slot's live pool holds, and re-allocation of all pools with a larger capacity
+ * (trees kept).  The single-game MCT mirror grows its pools before a search could exhaust them. */
+int az_engine_nodes_used(az_engine *e, int32_t slot, int32_t *n_nodes);
+int az_engine_grow_pools(az_engine *e, int32_t node_capacity);
 
 /* ---- arena support: Arena.play_game(s) (arena.py:36-185) for all slots at once -----------
  * h_sides[g] = +1/-1: the colour this engine searches for in slot g (0 = both colours, self-play).  az_engine_search

@@ -1070,7 +1070,7 @@ int orc_mct_choose(orc_mct *t, const orc_board *rootb, double temp, double *pi, 
 /* RandomPlayer (kind 0, players.py:76-94: board.get_random_move) / GreedyPlayer (kind 1, players.py:97-123: best
  * -get_score() of the position after the move, fair_max among equals) for the side to move.  The uniform draw among the
  * candidates (ascending action order) is keyed like the HIP engine's k_baseline_moves. */
-int orc_baseline_move(const orc_board *b, int kind, uint32_t seed, uint32_t game_id, int ply) {
+int orc_baseline_move(const orc_board *b, int kind, uint32_t seed, uint32_t game_id, int ply, int tie_mode) {
     int legal[ORC_MAX_ACTIONS], cand[ORC_MAX_ACTIONS], nc = 0;
     int k = orc_legal_moves(b, 0, legal);
     if (k <= 0) return -1;
@@ -1087,6 +1087,7 @@ int orc_baseline_move(const orc_board *b, int kind, uint32_t seed, uint32_t game
             if (sc == best) cand[nc++] = legal[i];
         }
     }
+    if (kind == 1 && tie_mode == ORC_TIE_LOWEST) return cand[0]; /* the reference's fair_max patched to the lowest action (golden G7) */
     uint32_t r[4];
     orc_philox4x32(seed, game_id, (uint32_t)ply, 0xFFFEu, P_TIE_MOVE, (uint32_t)kind, r);
     return cand[(uint32_t)(((uint64_t)r[0] * (uint32_t)nc) >> 32)];

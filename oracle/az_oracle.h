@@ -127,7 +127,7 @@ int orc_mct_n_nodes(const orc_mct *t);
 int64_t orc_mct_n_evals(const orc_mct *t);
 int orc_mct_max_path_len(const orc_mct *t); /* longest root..leaf path (in nodes) of any simulation since the last reset */
 /* RandomPlayer (kind 0) / GreedyPlayer (kind 1) move for the side to move (players.py:76-123); -1 if no move */
-int orc_baseline_move(const orc_board *b, int kind, uint32_t seed, uint32_t game_id, int ply);
+int orc_baseline_move(const orc_board *b, int kind, uint32_t seed, uint32_t game_id, int ply, int tie_mode);
 
 /* ---- self-play (trainer.py:215-273) -------------------------------------- */
 typedef struct {

@@ -118,7 +118,7 @@ def lib():
     L.orc_mct_n_evals.argtypes = [C.c_void_p]
     L.orc_mct_n_evals.restype = C.c_int64
     L.orc_mct_max_path_len.argtypes = [C.c_void_p]
-    L.orc_baseline_move.argtypes = [bp, C.c_int, C.c_uint32, C.c_uint32, C.c_int]
+    L.orc_baseline_move.argtypes = [bp, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
     L.orc_selfplay.argtypes = [C.POINTER(SelfplayCfg), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     L.orc_selfplay.restype = C.c_int64
@@ -153,9 +153,9 @@ def legal_moves(b, player=0):
     return list(out[:k])
 
 
-def baseline_move(b, kind, seed, game_id, ply):
+def baseline_move(b, kind, seed, game_id, ply, tie_mode=TIE_RANDOM):
     """RandomPlayer ('random') / GreedyPlayer ('greedy') move for the side to move (players.py:76-123)"""
-    return lib().orc_baseline_move(C.byref(b), {"random": 0, "greedy": 1}[kind], seed, game_id, ply)
+    return lib().orc_baseline_move(C.byref(b), {"random": 0, "greedy": 1}[kind], seed, game_id, ply, tie_mode)
 
 
 def fakenet(b):
@@ -365,13 +365,15 @@ def random_positions(game_id, H, W, seed, n_games, cap):
     return grids[:n], players[:n], actions[:n]
 
 
-def arena_games(dims, ev1, n_sim, opponent, opp_sim, seed, n_rounds, start_player=None, rounds=None):
+def arena_games(dims, ev1, n_sim, opponent, opp_sim, seed, n_rounds, start_player=None, rounds=None, tie_mode=TIE_RANDOM):
     """Arena.play_games (arena.py:36-185) restated on the oracle: player 1 is an AlphaZero tree (evaluator ev1, no noise,
     temperature 0: what AlphaZeroTrainer.evaluate builds, trainer.py:421-425); `opponent` is "random" / "greedy"
     (players.py:76-123), "mcts" (rollout MCTSPlayer) or another evaluator tuple.  Each side owns a tree and BOTH trees
     receive every move (arena.py:98-99).  Returns (moves per game, winners, scores, stats dict of arena.py:141-147).
     `rounds`: play only these round indices of the n_rounds (rounds are independent given (seed, round)): the lists and the stats
-    then cover those rounds, in that order -- how a test follows a few games of an arena too large to replay whole."""
+    then cover those rounds, in that order -- how a test follows a few games of an arena too large to replay whole.
+    tie_mode=TIE_LOWEST: fair_max replaced by "lowest action among the maxima" in the trees and in the greedy player: the mode
+    golden G7 (the reference's Arena.play_games under that patch) is recorded in."""
     from collections import defaultdict
     gid, H, W = dims
     p2_starts = [{1: False, 2: True}.get(start_player, bool(r % 2)) for r in range(n_rounds)]
@@ -380,12 +382,12 @@ def arena_games(dims, ev1, n_sim, opponent, opp_sim, seed, n_rounds, start_playe
     for r in played:
         side1 = -1 if p2_starts[r] else 1
         game_id = (r + seed * 100003) & 0xFFFFFFFF
-        t1 = MCT(ev1, eval_method=EVAL_NEURAL, tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed, game_id=game_id)
+        t1 = MCT(ev1, eval_method=EVAL_NEURAL, tie_mode=tie_mode, noise_mode=NOISE_OFF, seed=seed, game_id=game_id)
         t2 = None
         if opponent == "mcts":
-            t2 = MCT(("fake", None), eval_method=EVAL_ROLLOUT, tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed + 1, game_id=game_id)
+            t2 = MCT(("fake", None), eval_method=EVAL_ROLLOUT, tie_mode=tie_mode, noise_mode=NOISE_OFF, seed=seed + 1, game_id=game_id)
         elif not isinstance(opponent, str):
-            t2 = MCT(opponent, eval_method=EVAL_NEURAL, tie_mode=TIE_RANDOM, noise_mode=NOISE_OFF, seed=seed + 1, game_id=game_id)
+            t2 = MCT(opponent, eval_method=EVAL_NEURAL, tie_mode=tie_mode, noise_mode=NOISE_OFF, seed=seed + 1, game_id=game_id)
         b = new_board(gid, H, W)
         ply, moves = 0, []
         while not lib().orc_is_over(C.byref(b)):
@@ -396,7 +398,7 @@ def arena_games(dims, ev1, n_sim, opponent, opp_sim, seed, n_rounds, start_playe
                 t.search(b, ns)
                 a = t.choose(b, 0.0)[0]
             else:
-                a = baseline_move(b, opponent, seed + 7, game_id, ply)
+                a = baseline_move(b, opponent, seed + 7, game_id, ply, tie_mode)
             if lib().orc_play(C.byref(b), a) != 0:
                 raise RuntimeError("oracle arena: illegal move")
             t1.change_root(a)

@@ -83,3 +83,31 @@ def test_forced_collectives_world1_gloo():
     ret = mgr.dict()
     mp.spawn(_worker_one, args=(1, 29534, ret), nprocs=1, join=True)
     assert ret[0]
+
+
+def _worker_setup(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from alphazero_amd.games.othello import OthelloConfig
+    from alphazero_amd.trainer import AlphaZeroTrainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = AlphaZeroTrainer(verbose=False)
+    tr.game = "othello"
+    tr.config = OthelloConfig(board_size=6, simulations=4, episodes=4, do_eval=True, eval_opponent="previous", eval_episodes=2, device="cpu")
+    torch.manual_seed(1000 + rank)  # every rank draws its own initialisation
+    tr.setup()
+    ret[rank] = {k: v.clone() for k, v in tr.nn.state_dict().items()}
+    dist.destroy_process_group()
+
+
+def test_trainer_setup_hands_rank0_weights_to_every_rank():
+    """without the broadcast in setup() wave 0 of a multi-GPU job plays with a different network per rank"""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_setup, args=(world, 29535, ret), nprocs=world, join=True)
+    assert all(torch.equal(ret[0][k], ret[1][k]) for k in ret[0])
+    from alphazero_amd.games.othello import OthelloConfig
+    from alphazero_amd.games.registers import NETWORKS_REGISTER
+    torch.manual_seed(1000)
+    want = NETWORKS_REGISTER["othello"](config=OthelloConfig(board_size=6)).state_dict()
+    assert all(torch.equal(ret[0][k], want[k]) for k in want)

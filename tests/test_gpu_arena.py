@@ -119,3 +119,42 @@ def test_trainer_evaluates_against_the_previous_network(tmp_path):
     assert res == {k: dict(v) for k, v in ostats.items() if k.endswith("_starts")}
     tr.save_training_stats("prev-test")
     assert json.load(open(os.path.join(tmp_path, "prev-test", "eval.json")))["eval_opponent"] == "previous"
+
+
+@pytest.mark.parametrize("tag", ["tictactoe", "connect4", "othello6", "othello8"])
+def test_batched_arena_equals_the_reference_arena_fixture(tag):
+    """golden G7 directly (no oracle in between): the reference's Arena.play_games -- AlphaZeroPlayer on the closed-form fake network
+    against GreedyPlayer / another AlphaZeroPlayer under the deterministic fair_max -- move for move, winners, scores, stats dict,
+    on Othello 8x8 too"""
+    from conftest import TAGS
+    from test_oracle_arena import arena_fixture, same_stats
+    from alphazero_amd import engine as E
+    game, gid, H, W, A, n = TAGS[tag]
+    for p in arena_fixture(tag):
+        arena = BatchedArena(game, "fake", opponent=p["opponent"], n_sim=p["sims1"], opponent_n_sim=p["sims2"] or None, seed=0, board_size=n)
+        arena.tie_mode = E.TIE_LOWEST
+        stats = arena.play_games(p["n_rounds"], start_player=p["start_player"], return_stats=True, record_moves=True)
+        got = [[int(m[g]) for m in arena.moves if m[g] >= 0] for g in range(p["n_rounds"])]
+        assert got == p["moves"], (tag, p["opponent"])
+        assert same_stats(stats, p["stats"]), (tag, stats, p["stats"])
+
+
+def test_batched_arena_equals_oracle_arena_on_othello8():
+    """the BASELINE board: real OthelloNet(n=8) against greedy and against another network, move for move"""
+    from alphazero_amd.games.othello import OthelloNet
+    for opp_kind in ("greedy", "network"):
+        torch.manual_seed(61)
+        net = OthelloNet(n=8).eval()
+        ev1 = ("conv", O.ConvNet(O.OTHELLO, 8, 8, _np_sd(net)))
+        if opp_kind == "network":
+            torch.manual_seed(62)
+            net2 = OthelloNet(n=8).eval()
+            opp_engine, opp_oracle = net2, ("conv", O.ConvNet(O.OTHELLO, 8, 8, _np_sd(net2)))
+        else:
+            opp_engine = opp_oracle = "greedy"
+        arena = BatchedArena("othello", net, opponent=opp_engine, n_sim=12, opponent_n_sim=10, seed=9, board_size=8)
+        stats = arena.play_games(8, return_stats=True, record_moves=True)
+        got = [[int(m[g]) for m in arena.moves if m[g] >= 0] for g in range(8)]
+        moves, winners, scores, ostats = oracle_arena((O.OTHELLO, 8, 8), ev1, 12, opp_oracle, 10, 9, 8)
+        assert got == moves, opp_kind
+        assert stats["draw"] == ostats["draw"] and stats["player1"] == ostats["player1"] and stats["player2"] == ostats["player2"]

@@ -1,0 +1,146 @@
+"""Round-3 GPU tests: BASELINE config 5 (the trainer loop on Othello 8x8) against the oracle, the self-launching multi-rank bench in
+rehearsal mode, and the single-game MCT's device storage (reset across boards, searches accumulating on one root)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import oracle as O
+from alphazero_amd import base
+from alphazero_amd.games.othello import OthelloBoard, OthelloConfig
+from alphazero_amd.trainer import AlphaZeroTrainer
+
+pytestmark = pytest.mark.gpu
+
+
+def _np_sd(module):
+    return {k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items() if not k.endswith("num_batches_tracked")}
+
+
+def test_config5_train_loop_on_othello8_equals_oracle(tmp_path):
+    """BASELINE config 5 (trainer.py:475-572) through AlphaZeroTrainer.train() on Othello 8x8, reduced episodes, 2 iterations,
+    evaluation against the PREVIOUS network: iteration-1 samples == the oracle's self-play with the TRAINED weights, every evaluation
+    game == the oracle's arena between the two networks of that iteration, files written."""
+    base.DEFAULT_MODELS_PATH = str(tmp_path) + "/"
+    cfg = OthelloConfig(board_size=8, simulations=12, episodes=12, epochs=1, batch_size=64, iterations=2, do_eval=True, eval_opponent="previous",
+                        eval_episodes=4, device="cuda", save=True, save_checkpoints=True)
+    path = os.path.join(tmp_path, "cfg.json")
+    json.dump(cfg.to_dict(), open(path, "w"))
+    tr = AlphaZeroTrainer(verbose=False, engine_slots=16, seed=11, materialize_memory=False)
+    snaps, evals = [], []
+    orig_update, orig_eval = tr.update_network, tr.evaluate
+
+    def update_network(it):
+        orig_update(it)
+        snaps.append((_np_sd(tr.prev_nn), _np_sd(tr.nn)))  # (the network self-play used, the trained one)
+
+    def evaluate(it):
+        orig_eval(it)
+        evals.append(dict(tr.eval_results["results"][it]))
+    tr.update_network, tr.evaluate = update_network, evaluate
+    samples = []
+    orig_sp = tr.self_play
+
+    def self_play(it):
+        orig_sp(it)
+        samples.append({k: v.cpu().numpy().copy() for k, v in tr.device_samples.items()})
+    tr.self_play = self_play
+    torch.manual_seed(3)
+    tr.train(game="othello", experiment_name="o8", json_config_file=path)
+    assert len(snaps) == 2 and len(samples) == 2
+    tk = dict(temp_max_step=cfg.temp_max_step, temp_min_step=cfg.temp_min_step)
+    for it in range(2):
+        played_with = snaps[it][0]
+        ref = O.selfplay(O.OTHELLO, 8, 8, 12, 12, ("conv", O.ConvNet(O.OTHELLO, 8, 8, played_with)), seed=11, first_game_id=12 * it, **tk)
+        got = samples[it]
+        assert np.array_equal(got["state"], ref["state"]) and np.array_equal(got["pi"], ref["pi"]) and np.array_equal(got["z"], ref["z"]), it
+        assert np.array_equal(got["visits"], ref["visits"]) and np.array_equal(got["meta"][:, 0] + 12 * it, ref["meta"][:, 0])
+        # evaluation: the trained network (player 1) against the one it replaced, BatchedArena seed = trainer seed + iteration
+        new, old = snaps[it][1], snaps[it][0]
+        _, _, _, ostats = O.arena_games((O.OTHELLO, 8, 8), ("conv", O.ConvNet(O.OTHELLO, 8, 8, new)), 12, ("conv", O.ConvNet(O.OTHELLO, 8, 8, old)), 12,
+                                        seed=11 + it, n_rounds=4)
+        want = {k: dict(v) if hasattr(v, "items") else v for k, v in ostats.items() if k not in ("player1", "player2", "draw")}
+        assert evals[it] == want, (it, evals[it], want)
+    assert not np.array_equal(snaps[0][0]["fc1.weight"], snaps[0][1]["fc1.weight"])  # training moved the weights
+    assert np.array_equal(snaps[1][0]["fc1.weight"], snaps[0][1]["fc1.weight"])      # iteration 1 played with iteration 0's result
+    d = os.path.join(tmp_path, "o8")
+    for f in ("config.json", "loss.json", "eval.json", "o8.pt", "checkpoints/o8-chkpt-1.pt", "checkpoints/o8-chkpt-2.pt"):
+        assert os.path.exists(os.path.join(d, f)), f
+    loss = json.load(open(os.path.join(d, "loss.json")))
+    assert set(loss) == {"0", "1"} and len(loss["0"]["0"]["pi"]) == tr.device_memory["z"].shape[0] // 64 or len(loss["1"]["0"]["pi"]) > 0
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` started plainly (no torch.distributed.run) spawns its two ranks itself; rehearsal mode (gloo, both
+    ranks on this box's one GPU) with tiny sizes.  The line must say n_gpus 2, carry per-rank times and the config3 / config5 objects."""
+    env = dict(os.environ, AZ_BENCH_BACKEND="gloo", AZ_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--games", "64", "--sims", "8",
+           "--config3-total", "128", "--config5-episodes", "64"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["unit"] == "games/s" and out["value"] > 0
+    assert len(out["per_rank_ms_per_step"]) == 2 and len(out["per_rank_gather_ms_per_step"]) == 2
+    assert out["config3"]["n_gpus"] == 2 and out["config3"]["concurrent_games_per_gpu"] == 64 and out["config3"]["value"] > 0
+    v = out["config5"]["variants"]
+    assert set(v) == {"reference_batch_64", "batch_512"} and all(len(x["iterations"]) == 2 for x in v.values())
+    assert all(it["seconds"]["optimize_network"] > 0 and it["eval_results"] for x in v.values() for it in x["iterations"])
+    assert out["roofline"]["frac"] <= 1.0 and "end_to_end_frac" in out["roofline"]
+
+
+def test_bench_fails_when_a_rank_fails():
+    """a rank that dies takes the job down with a non-zero exit code (no hang, no half a JSON line)"""
+    env = dict(os.environ, AZ_BENCH_BACKEND="gloo", AZ_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--games", "64", "--sims", "0"]  # n_sim = 0: refused
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_player_reset_between_games_on_different_boards():
+    """reset() keeps the device storage; the reference's reset() yields a tree usable on ANY board -- an engine built for
+    one board must not search another (wrong rules / a crash in set_roots)"""
+    from alphazero_amd.games.connect4 import Connect4Board
+    from alphazero_amd.games.tictactoe import TicTacToeBoard
+    from alphazero_amd.players import MCTSPlayer
+    np.random.seed(0)
+    pl = MCTSPlayer(n_sim=30)
+    for board in (OthelloBoard(n=8), OthelloBoard(n=6), Connect4Board(width=7, height=6), TicTacToeBoard(), OthelloBoard(n=8)):
+        pl.reset()
+        for _ in range(3):
+            mv, probs, visits, _ = pl.get_move(board)
+            assert board.is_legal_move(mv) and sum(visits.values()) >= 29  # the kept subtree's visits count too
+            board.play_move(mv)
+            pl.apply_move(mv)
+
+
+def test_searches_accumulate_on_one_root():
+    """200 searches of 100 simulations without a move: the reference's tree keeps growing (mcts.py:226-269); the device pools are
+    grown on demand and keep the tree -- root N counts every simulation, children N sum up"""
+    from alphazero_amd.mcts import MCT
+    from alphazero_amd.games.othello import OthelloNet
+    torch.manual_seed(0)
+    mct = MCT(eval_method="neural", nn=OthelloNet(n=8).eval(), seed=5)
+    b = OthelloBoard(n=8)
+    cap0 = None
+    for i in range(200):
+        mct.search(b, n_sim=100)
+        if cap0 is None:
+            cap0 = mct._engine.cfg.node_capacity
+    a, n, q, p, root_n = mct._engine.root_children(0)
+    assert root_n == 200 * 100
+    assert n.sum() == 200 * 100 - 1  # the first simulation of a fresh root stops at the root (mcts.py:231-233)
+    assert mct._engine.cfg.node_capacity > cap0  # the pools really had to grow
+    # a wall-time bounded search on the same tree keeps working too
+    mct.search(b, compute_time=0.05)
+    assert mct._engine.root_children(0)[4] > root_n

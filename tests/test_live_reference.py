@@ -98,6 +98,34 @@ def test_committed_fixtures_are_what_the_reference_produces(R, tag, n_games, n_p
                 assert np.array_equal(new[k], old[k]), (name, k)
 
 
+@pytest.mark.parametrize("tag", ["tictactoe", "connect4", "othello6", "othello8"])
+def test_committed_arena_fixtures_are_what_the_reference_produces(R, tag, tmp_path, monkeypatch):
+    """golden G7 (Arena.play_games of the reference) re-generated and compared"""
+    from tools import gen_golden
+    monkeypatch.setattr(gen_golden, "GOLD", str(tmp_path))
+    gen_golden.gen_arena(R, tag)
+    new = np.load(os.path.join(tmp_path, f"arena_{tag}.npz"), allow_pickle=False)
+    old = np.load(os.path.join(os.path.dirname(__file__), "golden", f"arena_{tag}.npz"), allow_pickle=False)
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        assert np.array_equal(new[k], old[k]), (tag, k)
+
+
+def test_committed_sgd_fixture_of_the_baseline_network_is_what_the_reference_produces(R, tmp_path, monkeypatch):
+    """golden G6 for OthelloNet 8x8: the reference's optimize_network on the committed G4 memory"""
+    import shutil
+    from tools import gen_golden
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    shutil.copy(os.path.join(gold, "selfplay_othello8.npz"), tmp_path)
+    monkeypatch.setattr(gen_golden, "GOLD", str(tmp_path))
+    gen_golden.gen_sgd(R, "othello8")
+    new = np.load(os.path.join(tmp_path, "sgd_othello8.npz"), allow_pickle=False)
+    old = np.load(os.path.join(gold, "sgd_othello8.npz"), allow_pickle=False)
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        assert np.allclose(new[k], old[k], rtol=0, atol=1e-6), k
+
+
 def test_checkpoints_cross_load(R, tmp_path):
     """checkpoint wire format (base.py:288-325, trainer.py:448-473): models/<name>/{config.json,<name>.pt} written by either
     side load into the other and give the same network"""

@@ -133,6 +133,13 @@ for game, B in WORKLOADS:
                 ks[c + "_share_of_wave_cycles"] = ks[c] / ks["SQ_WAVE_CYCLES"]
     if ks:
         kstep[key] = ks
+sys.path.insert(0, root)
+from alphazero_amd._lib import csrc_tree_hash  # noqa: E402
+
+# the hash of the sources the measured library was built from: bench.py uses a counter file only for the same tree
+for d in (traffic, mfma, kstep):
+    if d:
+        d["csrc_sha"] = csrc_tree_hash()
 if traffic:
     json.dump(traffic, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
 if mfma:
@@ -144,4 +151,4 @@ if rows:
         fh.write("workload,kernel,counter,mean_per_launch,launches\n")
         for r in rows:
             fh.write(",".join(str(x) for x in r) + "\n")
-print("collected", tag, "traffic", list(traffic), "mfma", list(mfma), "kstep", list(kstep))
+print("collected", tag, "csrc", csrc_tree_hash(), "traffic", list(traffic), "mfma", list(mfma), "kstep", list(kstep))

@@ -11,6 +11,9 @@ the two-line shim of SURVEY.md Appendix B and records small fixtures under tests
   G4 selfplay_<game>.npz AlphaZeroTrainer.self_play memory (samples before/after normalise and
                          after the symmetry augmentation) under the same patches
   G5 stats.npz           outcome statistics of reference rollout-MCTS TicTacToe self-play
+  G7 arena_<game>.npz    Arena.play_games (arena.py:119-185) between AlphaZeroPlayer (closed-form fake net, no noise) and GreedyPlayer /
+                         another AlphaZeroPlayer under the deterministic fair_max: every move of every round, who started, winners,
+                         scores and the stats dict
   G6 sgd_<game>.npz      AlphaZeroTrainer.optimize_network (trainer.py:320-381): per-batch policy / value losses of two
                          epochs on the G4 memory and the trained fc1 / value-head weights (closed-form initial weights,
                          dropout 0, np.random.seed pinned for the batch shuffle)
@@ -48,8 +51,9 @@ def load_reference():
     import alphazero.trainer as trainer
     import alphazero.schedulers as schedulers
     import alphazero.games.registers as registers
+    import alphazero.arena as arena
     return types.SimpleNamespace(oth=oth, c4=c4, ttt=ttt, mcts=mcts, players=players, trainer=trainer,
-                                 schedulers=schedulers, registers=registers)
+                                 schedulers=schedulers, registers=registers, arena=arena)
 
 
 GAMES = {
@@ -236,14 +240,16 @@ class Patches:
         return last
 
     def __enter__(self):
-        self._orig = dict(fm=self.R.mcts.fair_max, dr=np.random.dirichlet, ch=np.random.choice)
+        self._orig = dict(fm=self.R.mcts.fair_max, fmp=self.R.players.fair_max, dr=np.random.dirichlet, ch=np.random.choice)
         self.R.mcts.fair_max = self.fair_max_lowest
+        self.R.players.fair_max = self.fair_max_lowest  # GreedyPlayer (players.py:97-123)
         np.random.dirichlet = self.dirichlet
         np.random.choice = self.choice
         return self
 
     def __exit__(self, *a):
         self.R.mcts.fair_max = self._orig["fm"]
+        self.R.players.fair_max = self._orig["fmp"]
         np.random.dirichlet = self._orig["dr"]
         np.random.choice = self._orig["ch"]
 
@@ -370,9 +376,63 @@ def gen_selfplay(R, tag, episodes, sims, seed=7):
     print(f"selfplay_{tag}: {n_orig} samples (+{len(mem) - n_orig} augmented), transformations={transf}")
 
 
+# ------------------------------------------------------------------------------------------- G7
+ARENA_PLAN = {  # tag: [(opponent, sims of player 1, sims of the opponent, rounds, start_player)]
+    "tictactoe": [("greedy", 20, 0, 6, None), ("alphazero", 20, 8, 4, None), ("greedy", 10, 0, 2, 2)],
+    "connect4": [("greedy", 20, 0, 4, None), ("alphazero", 20, 8, 4, None), ("alphazero", 10, 10, 2, 1)],
+    "othello6": [("greedy", 16, 0, 4, None), ("alphazero", 16, 6, 4, None), ("greedy", 8, 0, 2, 2)],
+    "othello8": [("greedy", 10, 0, 2, None), ("alphazero", 10, 5, 2, None)],
+}
+
+
+def gen_arena(R, tag):
+    """the reference's Arena.play_games, every move logged (Board.play_move of the arena's own board)"""
+    game, kw, A, n = GAMES[tag]
+    rec = {k: [] for k in ("opponent", "sims1", "sims2", "n_rounds", "start_player", "round_off", "moves", "move_off", "p2_starts", "winner_colour",
+                           "score", "p1_scores", "p1_off", "p2_scores", "p2_off", "draws", "starts")}
+    rec["round_off"].append(0); rec["move_off"].append(0); rec["p1_off"].append(0); rec["p2_off"].append(0)
+    enc = lambda sc: 32767 if sc == float("inf") else int(sc)  # noqa: E731
+    with Patches(R, tag) as P:
+        for opp, s1, s2, rounds, start in ARENA_PLAN[tag]:
+            p1 = R.players.AlphaZeroPlayer(n_sim=s1, nn=fake_net_class(R, tag))
+            p2 = R.players.GreedyPlayer() if opp == "greedy" else R.players.AlphaZeroPlayer(n_sim=s2, nn=fake_net_class(R, tag))
+            board = make_board(R, tag)
+            arena = R.arena.Arena(p1, p2, board)
+            log, finals = [], []
+            orig_play, orig_game = board.play_move, arena.play_game
+
+            def play_move(move, _o=orig_play, _l=log):
+                _l.append(P.act(move))
+                _o(move)
+
+            def play_game(player2_starts=False, **kwargs):
+                log.clear()
+                res = orig_game(player2_starts=player2_starts, **kwargs)
+                finals.append((list(log), bool(player2_starts), int(board.get_winner()), enc(abs(board.get_score()))))
+                return res
+            board.play_move, arena.play_game = play_move, play_game
+            stats = arena.play_games(n_rounds=rounds, start_player=start, return_stats=True)
+            assert len(finals) == rounds
+            rec["opponent"].append(0 if opp == "greedy" else 1); rec["sims1"].append(s1); rec["sims2"].append(s2)
+            rec["n_rounds"].append(rounds); rec["start_player"].append(0 if start is None else start)
+            for moves, p2s, win, sc in finals:
+                rec["moves"].extend(moves); rec["move_off"].append(len(rec["moves"]))
+                rec["p2_starts"].append(p2s); rec["winner_colour"].append(win); rec["score"].append(sc)
+            rec["round_off"].append(len(rec["p2_starts"]))
+            rec["p1_scores"].extend(enc(x) for x in stats["player1"]); rec["p1_off"].append(len(rec["p1_scores"]))
+            rec["p2_scores"].extend(enc(x) for x in stats["player2"]); rec["p2_off"].append(len(rec["p2_scores"]))
+            rec["draws"].append(stats["draw"])
+            rec["starts"].append([stats[f"player{p}_starts"].get(k, 0) for p in (1, 2) for k in ("win", "loss", "draw")])
+    np.savez_compressed(os.path.join(GOLD, f"arena_{tag}.npz"),
+                        **{k: np.array(v, np.int8 if k in ("opponent", "p2_starts", "winner_colour", "start_player") else np.int32) for k, v in rec.items()})
+    print(f"arena_{tag}: {len(rec['n_rounds'])} pairings, {len(rec['p2_starts'])} rounds, {len(rec['moves'])} moves, winners {rec['winner_colour']}")
+
+
 # ------------------------------------------------------------------------------------------- G6
 SGD_PLAN = {"tictactoe": dict(batch_size=16, epochs=2, shuffle_seed=4242), "connect4": dict(batch_size=32, epochs=2, shuffle_seed=4243),
-            "othello6": dict(batch_size=32, epochs=2, shuffle_seed=4244)}
+            "othello6": dict(batch_size=32, epochs=2, shuffle_seed=4244),
+            # the BASELINE network at the reference's batch size (othello.py:35): one epoch = 14 steps over the 940 G4 samples
+            "othello8": dict(batch_size=64, epochs=1, shuffle_seed=4245)}
 
 
 def gen_sgd(R, tag):
@@ -455,6 +515,9 @@ def main():
     for tag in SGD_PLAN:
         if not want or "sgd" in want or f"sgd_{tag}" in want:
             gen_sgd(R, tag)
+    for tag in ARENA_PLAN:
+        if not want or "arena" in want or f"arena_{tag}" in want:
+            gen_arena(R, tag)
 
 
 if __name__ == "__main__":
