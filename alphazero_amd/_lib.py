@@ -40,6 +40,8 @@ SYMBOLS = [
     "az_engine_get_stats", "az_engine_samples", "az_engine_set_roots", "az_engine_search", "az_engine_advance",
     "az_engine_root_children", "az_engine_nodes_used", "az_engine_grow_pools", "az_engine_play", "az_augment_count", "az_augment",
     "az_engine_set_sides", "az_engine_best_moves", "az_engine_baseline_moves", "az_engine_root_status",
+    "az_trainer_create", "az_trainer_destroy", "az_trainer_load", "az_trainer_store", "az_trainer_begin", "az_trainer_set_lr",
+    "az_trainer_steps", "az_trainer_debug",
 ]
 
 
@@ -93,6 +95,15 @@ def lib():
     L.az_engine_root_children.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.az_engine_nodes_used.argtypes = [vp, i32, C.POINTER(i32)]
     L.az_engine_grow_pools.argtypes = [vp, i32]
+    L.az_trainer_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.az_trainer_destroy.argtypes = [vp]
+    L.az_trainer_destroy.restype = None
+    L.az_trainer_load.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    L.az_trainer_store.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    L.az_trainer_begin.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, vp]
+    L.az_trainer_set_lr.argtypes = [vp, C.c_float, vp]
+    L.az_trainer_steps.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.az_trainer_debug.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)]
     _LIB = L
     return L
 

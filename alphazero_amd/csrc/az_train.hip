@@ -1,0 +1,1393 @@
+// az_train.hip -- the optimisation step of AlphaZeroTrainer.optimize_network (trainer.py:320-381) on MI355X (gfx950):
+// forward in TRAIN mode (BatchNorm batch statistics, dropout), loss, backward and the momentum-SGD update of OthelloNet /
+// Connect4Net (othello.py:341-382, connect4.py:370-412) as fifteen hand-written kernels per step, float32 in / float32
+// accumulate on the f32-input matrix cores (v_mfma_f32_16x16x4_f32), on device-resident samples.
+//
+//   loss   = -sum(pi * log_softmax(logits)) / B + sum((tanh(u) - z)^2) / B                       (trainer.py:352-354)
+//   update = torch.optim.SGD(lr, momentum, weight_decay): g += wd p;  m = mu m + g;  p -= lr m  (trainer.py:326), on EVERY parameter
+//   BatchNorm (train): batch mean / biased variance, eps 1e-5; running stats <- 0.9 old + 0.1 (mean, unbiased variance)
+//   dropout p on the two dense layers: a Philox4x32-10 mask keyed (seed, step, layer, element) -- torch's own stream cannot be matched
+//
+// Why fifteen launches and no persistent kernel: train-mode BatchNorm puts a batch-wide reduction behind every layer, forward and
+// backward.  A dependent kernel boundary costs ~1.5 us on this chip, a grid-wide barrier inside one launch ~4-5 us
+// (MI355X_MICROARCH.md, rows "boundary" / "barrier-xcd"), so the reductions are cut at launch boundaries: every kernel leaves
+// per-workgroup partials (count / mean / M2 for the forward statistics, double sums for the backward ones), the consumer combines
+// them in a fixed order -- deterministic, no float atomics.  The step's launch parameters never change (step counter, learning rate,
+// permutation offset and loss slot live in device memory), so the host captures it once as a HIP graph and replays it.
+//
+// Layout: activations are NHWC ([board][position][32 channels]); the flatten in front of fc1 is the reference's NCHW order, so
+// fc1.weight is held with its input index permuted (k = position * 32 + channel) and permuted back on export.
+//   kernel            grid                         work
+//   k_conv1_fwd       boards                       gather int8 state -> conv1 (VALU, K = 9) -> c1 + statistics partial
+//   k_conv_fwd x3     boards                       BN+ReLU of the previous layer on load -> implicit GEMM on MFMA -> c_l + partial
+//   k_fc_fwd x2       16 columns per workgroup     (BN4+ReLU on load) GEMM over all rows -> column statistics -> BN1d, ReLU, dropout
+//   k_heads_fwd       16 rows per workgroup        logits, log_softmax, tanh, the two loss sums, d loss / d logits
+//   k_heads_bwd       16 columns of fc2            d h2, fc_bn2 backward, heads weight gradient + update
+//   k_fc_dgrad        16 columns of fc1            d h1 (old W2), fc_bn1 backward
+//   k_mix1            tiles | 16 input columns     fc2 weight gradient + update | d a4 (old W1), ReLU mask, column sums for bn4
+//   k_mix2            tiles | boards               fc1 weight gradient + update | conv4 backward (data + weight partials)
+//   k_conv_bwd x2     boards                       conv3 / conv2 backward
+//   k_conv1_bwd       boards                       conv1 weight partials
+//   k_update          elements                     conv weights / biases / BN2d affine: reduce partials + SGD; running stats; loss log; ++step
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "az_device.h"
+#include "az_host.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// MFMA 16x16x4 f32 operand layout (lane l): A[row l & 15][k l >> 4], B[k l >> 4][col l & 15], C/D[row 4 (l >> 4) + r][col l & 15]
+
+#ifdef AZ_TPROBE  // diagnostic build (make TPROBE=1): wall-clock stamps (100 MHz) of workgroup 0 at the phase boundaries of every kernel
+__device__ unsigned long long az_tprobe[32 * 16];
+#define TSTAMP(k, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) az_tprobe[(k) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TSTAMP(k, i)
+#endif
+
+#define NCH 32
+#define LDP 36        // LDS row stride of a 32-channel row: 36 = 4 mod 32 -> the 16 x 4 (row, k) lanes of an A fragment hit every bank twice
+#define TPB 256
+#define BN_EPS 1e-5
+#define BN_MOM 0.1
+#define FPART 65      // forward statistics partial: n, mean[32], M2[32]
+#define MAXB 512
+
+struct Hyper {        // device-resident so that a captured step never goes stale
+    float lr, momentum, wd, drop_p;
+    unsigned seed;
+    int step;         // steps done since az_trainer_begin (k_update increments it)
+    int perm_off;     // permutation entries consumed so far: row of board b = perm[perm_off + b]
+    int loss_off;     // slot of this step's losses in loss_pi / loss_v
+};
+
+struct PSet {         // one set of tensors in the step's own layout (parameters; the momentum buffers mirror it)
+    float *cw[4];     // conv1 [9][32 oc]; conv2..4 [9 taps][32 ic][32 oc]
+    float *cb[4];     // [32]
+    float *bg[4], *bb[4];   // BatchNorm2d weight / bias [32]
+    float *w1, *b1, *g1, *be1;  // fc1 [F1][FIN] (input index NHWC), fc_bn1
+    float *w2, *b2, *g2, *be2;  // fc2 [F2][F1], fc_bn2
+    float *wh, *bh;   // heads [NHP][F2]: rows 0..A-1 fc_probs, row A fc_value, rest zero; [NHP]
+};
+
+struct TDims {
+    int CH, CW, P1, H3, W3, P3, H4, W4, P4, FIN, F1, F2, A, NH, NHP;
+    int B;    // batch size (multiple of 16, <= MAXB)
+    int NB;   // workgroups of the per-board kernels = forward statistic partials per layer
+};
+
+struct TPtr {
+    PSet p, m;
+    float *rm[4], *rv[4], *rm1, *rv1, *rm2, *rv2;  // running statistics
+    const int8_t *state; const float *pi; const int8_t *z; const long long *perm;
+    float *loss_pi, *loss_v;
+    Hyper *hp;
+    float *x0, *c[4], *fpart[4];
+    float *y1, *h1, *mu1, *iv1, *y2, *h2, *mu2, *iv2, *dlog, *losspart;
+    float *dz2, *dz1, *dy[4];
+    double *bpart[3];   // backward sums of bn1..bn3: [NB][64] (sum dy, sum dy xhat per channel)
+    double *colsum;     // backward sums of bn4 per fc1 input column: [FIN][2]
+    float *gw[4];       // weight-gradient partials [NB][9*32*32 + 32] (conv1: [NB][9*32 + 32]): weights then bias
+};
+
+// ---------------------------------------------------------------------------------------------------------------- helpers
+AZ_D int conv_hin(const TDims &d, int l) { return l <= 2 ? d.CH : d.H3; }   // l = 1..3: conv2, conv3, conv4
+AZ_D int conv_win(const TDims &d, int l) { return l <= 2 ? d.CW : d.W3; }
+AZ_D int conv_hout(const TDims &d, int l) { return l == 1 ? d.CH : (l == 2 ? d.H3 : d.H4); }
+AZ_D int conv_wout(const TDims &d, int l) { return l == 1 ? d.CW : (l == 2 ? d.W3 : d.W4); }
+AZ_D int plane_of(const TDims &d, int l) { return l <= 1 ? d.P1 : (l == 2 ? d.P3 : d.P4); }  // positions of c[l], l = 0..3
+
+// Combination of the (n, mean, M2) partials of a layer in a fixed order: all TPB threads call; s_mean / s_var (biased) valid after
+// return.  One pass in double: N = sum n_p, S = sum n_p mean_p, Q = sum (M2_p + n_p mean_p^2); mean = S / N, M2 = Q - N mean^2 (the
+// subtraction costs log10(mean^2 / var) of double's 16 digits: harmless; the partials themselves are shifted sums, so nothing was lost
+// in float).  No division and no dependent load inside the loop.
+AZ_D void bn2d_combine(const float *part, int npart, float *s_mean, float *s_var, double *scr /* [8][32][3] */) {
+    const int t = threadIdx.x, ch = t & 31, grp = t >> 5;
+    double N = 0.0, S = 0.0, Q = 0.0;
+    if (t < 256) {  // the dense kernels run up to 1024 threads: the first 256 walk the partials
+#pragma unroll 4
+        for (int p = grp; p < npart; p += 8) {
+            const double nb = part[p * FPART], mb = part[p * FPART + 1 + ch], qb = part[p * FPART + 33 + ch];
+            N += nb; S += nb * mb; Q += qb + nb * mb * mb;
+        }
+        scr[(grp * 32 + ch) * 3 + 0] = N; scr[(grp * 32 + ch) * 3 + 1] = S; scr[(grp * 32 + ch) * 3 + 2] = Q;
+    }
+    __syncthreads();
+    if (t < 32) {
+        N = 0.0; S = 0.0; Q = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { N += scr[(g * 32 + ch) * 3]; S += scr[(g * 32 + ch) * 3 + 1]; Q += scr[(g * 32 + ch) * 3 + 2]; }
+        const double mean = S / N;
+        double M2 = Q - N * mean * mean;
+        if (M2 < 0.0) M2 = 0.0;
+        s_mean[ch] = (float)mean; s_var[ch] = (float)(M2 / N);
+    }
+    __syncthreads();
+}
+
+// scale / shift of train-mode BatchNorm2d l (0..3) from its forward partials; also mean / 1/sqrt(var + eps)
+AZ_D void bn2d_prepare(const TDims &d, const TPtr &q, int l, float *s_scale, float *s_shift, float *s_mean, float *s_inv, double *scr) {
+    bn2d_combine(q.fpart[l], d.NB, s_mean, s_inv, scr);
+    if (threadIdx.x < 32) {
+        const int ch = threadIdx.x;
+        const float inv = (float)(1.0 / sqrt((double)s_inv[ch] + BN_EPS));
+        const float sc = q.p.bg[l][ch] * inv;
+        s_inv[ch] = inv; s_scale[ch] = sc; s_shift[ch] = q.p.bb[l][ch] - s_mean[ch] * sc;
+    }
+    __syncthreads();
+}
+
+// per-channel (mean, M2) of an LDS plane pl[P][LDP] (two passes, double); every thread returns the values of channel t & 31
+AZ_D void plane_stats(const float *pl, int P, double *scr /* [8][32] */, double &mean, double &M2) {
+    const int t = threadIdx.x, ch = t & 31, grp = t >> 5;
+    double s = 0.0;
+    for (int p = grp; p < P; p += 8) s += pl[p * LDP + ch];
+    scr[grp * 32 + ch] = s;
+    __syncthreads();
+    double tot = 0.0;
+    for (int g = 0; g < 8; ++g) tot += scr[g * 32 + ch];
+    mean = tot / P;
+    __syncthreads();
+    double qq = 0.0;
+    for (int p = grp; p < P; p += 8) { const double dl = pl[p * LDP + ch] - mean; qq += dl * dl; }
+    scr[grp * 32 + ch] = qq;
+    __syncthreads();
+    M2 = 0.0;
+    for (int g = 0; g < 8; ++g) M2 += scr[g * 32 + ch];
+    __syncthreads();
+}
+
+AZ_D void chan_merge(double &n, double &mean, double &M2, double nb, double mb, double qb) {
+    const double nn = n + nb, dl = mb - mean;
+    mean += dl * nb / nn; M2 += qb + dl * dl * n * nb / nn; n = nn;
+}
+
+// per-channel sums of a plane and of plane x xhat over its positions (double), accumulated into the caller's registers (channel t & 31,
+// position group t >> 5: the cross-group reduction happens once, at the end of the kernel)
+AZ_D void plane_sums(const float *pl, const float *xh, int P, double &s1, double &s2) {
+    const int t = threadIdx.x, ch = t & 31, grp = t >> 5;
+    for (int p = grp; p < P; p += 8) { const double v = pl[p * LDP + ch]; s1 += v; s2 += v * (double)xh[p * LDP + ch]; }
+}
+
+// momentum SGD with weight decay on one element (torch.optim.SGD, dampening 0, no Nesterov)
+AZ_D void sgd(float *p, float *m, float g, const Hyper &hp) {
+    const float gg = fmaf(hp.wd, *p, g);
+    const float mm = fmaf(hp.momentum, *m, gg);
+    *m = mm;
+    *p = fmaf(-hp.lr, mm, *p);
+}
+
+AZ_D float dropout_scale(const Hyper &hp, int layer, unsigned idx) {  // 0 (dropped) or 1 / (1 - p)
+    if (hp.drop_p <= 0.0f) return 1.0f;
+    const Philox4 r = az_philox(hp.seed, 0x54524e00u + (u32)layer, (u32)hp.step, idx, 0x44524f50u, 0u);
+    const float u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+    return u < hp.drop_p ? 0.0f : 1.0f / (1.0f - hp.drop_p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- conv1 forward
+__global__ __launch_bounds__(TPB) void k_conv1_fwd(TDims d, TPtr q) {
+    __shared__ float xin[10 * 10];
+    __shared__ float wl[9 * 32], bl[32];
+    __shared__ float pl[64 * LDP];
+    __shared__ double scr[8 * 32];
+    const int t = threadIdx.x, WP = d.CW + 2;
+    const Hyper hp = *q.hp;
+    for (int i = t; i < 9 * 32; i += TPB) wl[i] = q.p.cw[0][i];
+    if (t < 32) bl[t] = q.p.cb[0][t];
+    for (int i = t; i < 100; i += TPB) xin[i] = 0.0f;
+    double n = 0.0, mean = 0.0, M2 = 0.0;
+    __syncthreads();
+    for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
+        const long long row = q.perm[hp.perm_off + b];
+        for (int p = t; p < d.P1; p += TPB) {
+            const float v = (float)q.state[row * d.P1 + p];
+            xin[(p / d.CW + 1) * WP + p % d.CW + 1] = v;
+            q.x0[b * d.P1 + p] = v;
+        }
+        __syncthreads();
+        for (int i = t; i < d.P1 * 32; i += TPB) {
+            const int p = i >> 5, oc = i & 31, r = p / d.CW, c = p % d.CW;
+            float acc = bl[oc];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc = fmaf(xin[(r + tap / 3) * WP + c + tap % 3], wl[tap * 32 + oc], acc);
+            q.c[0][((size_t)b * d.P1 + p) * 32 + oc] = acc;
+            pl[p * LDP + oc] = acc;
+        }
+        __syncthreads();
+        double mb, qb;
+        plane_stats(pl, d.P1, scr, mb, qb);
+        chan_merge(n, mean, M2, (double)d.P1, mb, qb);
+    }
+    if (t < 32) {
+        float *o = q.fpart[0] + (size_t)blockIdx.x * FPART;
+        if (t == 0) o[0] = (float)n;
+        o[1 + t] = (float)mean; o[33 + t] = (float)M2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- conv2..4 forward
+// implicit GEMM per board: M = output positions (tiles of 16), N = 32 oc (2 tiles), K = 9 taps x 32 ic.
+// LDS: wl[288][LDP] weights (row tap*32+ic, column oc) | ain[(Hin+2 pad)(Win+2 pad)][LDP] input activation with a zero halo | pl[64][LDP]
+#define CONV_FWD_LDS_FLOATS (288 * LDP + 100 * LDP + 64 * LDP + 4 * 32)
+#define CONV_FWD_LDS_BYTES (CONV_FWD_LDS_FLOATS * 4 + 8 * 32 * 3 * 8)
+__global__ __launch_bounds__(TPB) void k_conv_fwd(TDims d, TPtr q, int l /* 1..3 */) {
+    extern __shared__ __align__(16) float lds[];
+    float *wl = lds, *ain = wl + 288 * LDP, *pl = ain + 100 * LDP, *s_scale = pl + 64 * LDP, *s_shift = s_scale + 32, *s_mean = s_shift + 32,
+          *s_inv = s_mean + 32;
+    double *scr = (double *)(s_inv + 32);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
+    const int Hin = conv_hin(d, l), Win = conv_win(d, l), Hout = conv_hout(d, l), Wout = conv_wout(d, l), pad = l == 1 ? 1 : 0;
+    const int Pin = Hin * Win, Pout = Hout * Wout, WP = Win + 2 * pad, MT = (Pout + 15) / 16;
+    TSTAMP(1, 0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {  // 9216 floats as 2304 float4: nine per thread, all in flight at once
+        const int e = (i * TPB + t) * 4;
+        *(float4 *)(wl + (e >> 5) * LDP + (e & 31)) = *(const float4 *)(q.p.cw[l] + e);
+    }
+    for (int i = t; i < 100 * LDP; i += TPB) ain[i] = 0.0f;
+    TSTAMP(1, 1);
+    bn2d_prepare(d, q, l - 1, s_scale, s_shift, s_mean, s_inv, scr);
+    TSTAMP(1, 2);
+    const float *cin = q.c[l - 1];
+    float *cout = q.c[l];
+    double n = 0.0, mean = 0.0, M2 = 0.0;
+    for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
+        for (int i = t; i < Pin * 32; i += TPB) {
+            const int p = i >> 5, ic = i & 31;
+            const float v = fmaf(cin[(size_t)b * Pin * 32 + i], s_scale[ic], s_shift[ic]);
+            ain[((p / Win + pad) * WP + p % Win + pad) * LDP + ic] = v > 0.0f ? v : 0.0f;
+        }
+        __syncthreads();
+        TSTAMP(1, 3);
+        for (int mt = wave; mt < MT; mt += 4) {
+            int m = 16 * mt + n16;
+            if (m >= Pout) m = Pout - 1;  // rows beyond the plane compute a copy of the last position; never stored
+            const int base = (m / Wout) * WP + m % Wout;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float *ap = ain + (base + (tap / 3) * WP + tap % 3) * LDP + kq;
+                const float *wp = wl + (tap * 32 + kq) * LDP + n16;
+#pragma unroll
+                for (int icb = 0; icb < 8; ++icb) {
+                    const float a = ap[icb * 4];
+                    acc0 = MFMA(a, wp[icb * 4 * LDP], acc0);
+                    acc1 = MFMA(a, wp[icb * 4 * LDP + 16], acc1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mm = 16 * mt + 4 * kq + r;
+                if (mm < Pout) {
+                    const float v0 = acc0[r] + q.p.cb[l][n16], v1 = acc1[r] + q.p.cb[l][16 + n16];
+                    cout[((size_t)b * Pout + mm) * 32 + n16] = v0; cout[((size_t)b * Pout + mm) * 32 + 16 + n16] = v1;
+                    pl[mm * LDP + n16] = v0; pl[mm * LDP + 16 + n16] = v1;
+                }
+            }
+        }
+        __syncthreads();
+        TSTAMP(1, 4);
+        double mb, qb;
+        plane_stats(pl, Pout, scr, mb, qb);  // ends with a barrier: the next board may overwrite ain / pl
+        chan_merge(n, mean, M2, (double)Pout, mb, qb);
+        TSTAMP(1, 5);
+    }
+    if (t < 32) {
+        float *o = q.fpart[l] + (size_t)blockIdx.x * FPART;
+        if (t == 0) o[0] = (float)n;
+        o[1 + t] = (float)mean; o[33 + t] = (float)M2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dense layers: shared pieces
+// The dense kernels give a workgroup 16 output columns and ALL rows of the batch, so that the batch statistics of BatchNorm1d are
+// local to it; its NW waves split K, their partial sums meet in LDS.  At batch 64 every wave would otherwise walk K in a dozen
+// dependent round trips to L2 (measured: 1.2 us per 16-deep step), so (a) NW grows as the batch shrinks (16 waves at <= 64 rows), and
+// (b) a wave loads PF steps' worth of fragments before it issues their MFMAs.
+//   batch <= 64: RTM 4, NW 16, PF 2 | <= 128: 8, 8, 2 | <= 256: 16, 4, 2 | <= 512: 32, 4, 1        (red[NW][B][16] <= 128 KB)
+static inline int fc_lds_bytes(int NW, int B) { return (NW * B * 16 + 4 * 32) * 4 + 768 * 8; }
+
+// acc[rt] += A[16 rt + m][k] Bt[n][k] over k in [kbeg, kend): both operands k-contiguous, a lane loads four consecutive k as one float4
+// and feeds them to four MFMAs (the k index inside a step of 16 is 4 kq + i for A and B alike: the products pair up, only the
+// summation order differs from k ascending).  BNIN: A = relu(scale[k & 31] a + shift[k & 31]) (bn4 + ReLU formed on load).
+template <int RTM, int PF, bool BNIN>
+AZ_D void nt_kloop(f32x4 (&acc)[RTM], const float *A, int lda, const float *Brow, int RT, int kbeg, int kend, int n16, int kq,
+                   const float *s_scale, const float *s_shift) {
+    for (int k0 = kbeg; k0 < kend; k0 += 16 * PF) {
+        float4 bf[PF], af[PF][RTM];
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (k0 + 16 * p < kend) {
+                bf[p] = *(const float4 *)(Brow + k0 + 16 * p + 4 * kq);
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+                    if (rt < RT) af[p][rt] = *(const float4 *)(A + (size_t)(16 * rt + n16) * lda + k0 + 16 * p + 4 * kq);
+            }
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (k0 + 16 * p < kend) {
+                float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+                if (BNIN) {
+                    const int c0 = (k0 + 16 * p + 4 * kq) & 31;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { sc[i] = s_scale[c0 + i]; sh[i] = s_shift[c0 + i]; }
+                }
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+                    if (rt < RT) {
+                        float4 a = af[p][rt];
+                        if (BNIN) {
+                            a.x = fmaxf(fmaf(a.x, sc[0], sh[0]), 0.f); a.y = fmaxf(fmaf(a.y, sc[1], sh[1]), 0.f);
+                            a.z = fmaxf(fmaf(a.z, sc[2], sh[2]), 0.f); a.w = fmaxf(fmaf(a.w, sc[3], sh[3]), 0.f);
+                        }
+                        acc[rt] = MFMA(a.x, bf[p].x, acc[rt]); acc[rt] = MFMA(a.y, bf[p].y, acc[rt]);
+                        acc[rt] = MFMA(a.z, bf[p].z, acc[rt]); acc[rt] = MFMA(a.w, bf[p].w, acc[rt]);
+                    }
+            }
+    }
+}
+
+// the same with B[k][n] stored k-major (row k of W, column k0c + n): one dword per MFMA for B, float4 per four MFMAs for A = dZ
+template <int RTM, int PF>
+AZ_D void nn_kloop(f32x4 (&acc)[RTM], const float *dZ, int J, const float *W, int ldw, int RT, int jbeg, int jend, int n16, int kq) {
+    for (int j0 = jbeg; j0 < jend; j0 += 16 * PF) {
+        float bw[PF][4];
+        float4 af[PF][RTM];
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (j0 + 16 * p < jend) {
+                const float *wp = W + (size_t)(j0 + 16 * p + 4 * kq) * ldw + n16;
+                bw[p][0] = wp[0]; bw[p][1] = wp[ldw]; bw[p][2] = wp[2 * (size_t)ldw]; bw[p][3] = wp[3 * (size_t)ldw];
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+                    if (rt < RT) af[p][rt] = *(const float4 *)(dZ + (size_t)(16 * rt + n16) * J + j0 + 16 * p + 4 * kq);
+            }
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (j0 + 16 * p < jend)
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+                    if (rt < RT) {
+                        acc[rt] = MFMA(af[p][rt].x, bw[p][0], acc[rt]); acc[rt] = MFMA(af[p][rt].y, bw[p][1], acc[rt]);
+                        acc[rt] = MFMA(af[p][rt].z, bw[p][2], acc[rt]); acc[rt] = MFMA(af[p][rt].w, bw[p][3], acc[rt]);
+                    }
+    }
+}
+
+// partial sums of the NW waves -> red[0][r][col] (element (r, col) is read and written by the one thread that owns it)
+template <int RTM, int NW>
+AZ_D void reduce_waves(f32x4 (&acc)[RTM], float *red, int B, int RT, int wave, int n16, int kq) {
+#pragma unroll
+    for (int rt = 0; rt < RTM; ++rt)
+        if (rt < RT)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)wave * B + 16 * rt + 4 * kq + r) * 16 + n16] = acc[rt][r];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 256) {
+        const int col = t & 15, rg = t >> 4;
+        for (int r = rg; r < B; r += 16) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[((size_t)w * B + r) * 16 + col];
+            red[r * 16 + col] = v;
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dense forward
+// y = A W^T + b for 16 columns n0.. and all rows, column statistics, BatchNorm1d (train), ReLU, dropout.
+// layer 1: A = relu(bn4(c4)) formed on load (channel = k & 31), layer 2: A = h1.
+template <int RTM, int NW, int PF>
+__global__ __launch_bounds__(NW * 64) void k_fc_fwd(TDims d, TPtr q, int layer) {
+    extern __shared__ __align__(16) float lds[];
+    const int B = d.B, RT = B / 16;
+    float *red = lds, *s_scale = red + NW * B * 16, *s_shift = s_scale + 32, *s_mean = s_shift + 32, *s_inv = s_mean + 32;
+    double *scr = (double *)(s_inv + 32);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
+    const int N = layer == 1 ? d.F1 : d.F2, K = layer == 1 ? d.FIN : d.F1, n0 = blockIdx.x * 16;
+    const float *A = layer == 1 ? q.c[3] : q.h1, *W = layer == 1 ? q.p.w1 : q.p.w2;
+    const Hyper hp = *q.hp;
+    TSTAMP(2, 0);
+    if (layer == 1) bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr);
+    TSTAMP(2, 1);
+    const int chunk = ((K / 16 + NW - 1) / NW) * 16, kbeg = wave * chunk, kend = min(K, kbeg + chunk);
+    f32x4 acc[RTM];
+#pragma unroll
+    for (int i = 0; i < RTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (layer == 1) nt_kloop<RTM, PF, true>(acc, A, K, W + (size_t)(n0 + n16) * K, RT, kbeg, kend, n16, kq, s_scale, s_shift);
+    else nt_kloop<RTM, PF, false>(acc, A, K, W + (size_t)(n0 + n16) * K, RT, kbeg, kend, n16, kq, nullptr, nullptr);
+    reduce_waves<RTM, NW>(acc, red, B, RT, wave, n16, kq);
+    TSTAMP(2, 2);
+    const bool act = t < 256;
+    const int col = t & 15, rg = (t >> 4) & 15, n = n0 + col;
+    const float bias = (layer == 1 ? q.p.b1 : q.p.b2)[n];
+    float v[RTM];
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < RTM; ++i)
+        if (i < RT) { v[i] = red[(rg + 16 * i) * 16 + col] + bias; s += v[i]; }
+    if (act) scr[rg * 16 + col] = s;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) tot += scr[g * 16 + col];
+    const double mean = tot / B;
+    __syncthreads();
+    double qq = 0.0;
+#pragma unroll
+    for (int i = 0; i < RTM; ++i)
+        if (i < RT) { const double dl = v[i] - mean; qq += dl * dl; }
+    if (act) scr[rg * 16 + col] = qq;
+    __syncthreads();
+    if (!act) return;
+    double M2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) M2 += scr[g * 16 + col];
+    const double var = M2 / B;
+    const float inv = (float)(1.0 / sqrt(var + BN_EPS)), mu = (float)mean;
+    const float g_ = (layer == 1 ? q.p.g1 : q.p.g2)[n], b_ = (layer == 1 ? q.p.be1 : q.p.be2)[n];
+    float *y = layer == 1 ? q.y1 : q.y2, *h = layer == 1 ? q.h1 : q.h2;
+#pragma unroll
+    for (int i = 0; i < RTM; ++i)
+        if (i < RT) {
+            const int r = rg + 16 * i;
+            y[(size_t)r * N + n] = v[i];
+            const float xh = (v[i] - mu) * inv;
+            float hh = fmaxf(fmaf(g_, xh, b_), 0.f);
+            hh *= dropout_scale(hp, layer, (unsigned)(r * N + n));
+            h[(size_t)r * N + n] = hh;
+        }
+    TSTAMP(2, 3);
+    if (rg == 0) {
+        (layer == 1 ? q.mu1 : q.mu2)[n] = mu;
+        (layer == 1 ? q.iv1 : q.iv2)[n] = inv;
+        float *rm = layer == 1 ? q.rm1 : q.rm2, *rv = layer == 1 ? q.rv1 : q.rv2;
+        rm[n] = (float)((1.0 - BN_MOM) * rm[n] + BN_MOM * mean);
+        rv[n] = (float)((1.0 - BN_MOM) * rv[n] + BN_MOM * (M2 / (B > 1 ? B - 1 : 1)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- heads forward + loss
+// 16 rows per workgroup: logits = h2 Wh^T + bh (K split over NW waves), log_softmax over the A policy columns, tanh of the
+// value column, the two loss sums of the rows and d loss / d logits (trainer.py:352-354 with B = config.batch_size)
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_heads_fwd(TDims d, TPtr q) {
+    __shared__ float red[NW][16][NT * 16];
+    __shared__ float lg[16][NT * 16 + 1];
+    __shared__ double rowl[16][2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
+    const int K = d.F2, r0 = blockIdx.x * 16, NHP = NT * 16, A = d.A;
+    const Hyper hp = *q.hp;
+    const int chunk = ((K / 16 + NW - 1) / NW) * 16, kbeg = wave * chunk, kend = min(K, kbeg + chunk);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {  // two steps of 16 per trip: all loads first
+        float4 af[2], bf[2][NT];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (k0 + 16 * p < kend) {
+                af[p] = *(const float4 *)(q.h2 + (size_t)(r0 + n16) * K + k0 + 16 * p + 4 * kq);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[p][nt] = *(const float4 *)(q.p.wh + (size_t)(16 * nt + n16) * K + k0 + 16 * p + 4 * kq);
+            }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (k0 + 16 * p < kend)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt] = MFMA(af[p].x, bf[p][nt].x, acc[nt]); acc[nt] = MFMA(af[p].y, bf[p][nt].y, acc[nt]);
+                    acc[nt] = MFMA(af[p].z, bf[p][nt].z, acc[nt]); acc[nt] = MFMA(af[p].w, bf[p][nt].w, acc[nt]);
+                }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][16 * nt + n16] = acc[nt][r];
+    __syncthreads();
+    for (int i = t; i < 16 * NHP; i += NW * 64) {
+        const int row = i / NHP, a = i % NHP;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][row][a];
+        lg[row][a] = v + q.p.bh[a];
+    }
+    __syncthreads();
+    if (t < 256) {
+        const int row = t >> 4, j = t & 15;
+        const long long brow = q.perm[hp.perm_off + r0 + row];
+        const float invB = 1.0f / (float)d.B;
+        float mx = -3.0e38f;
+        for (int a = j; a < A; a += 16) mx = fmaxf(mx, lg[row][a]);
+        for (int o = 8; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float se = 0.f, spi = 0.f;
+        for (int a = j; a < A; a += 16) { se += expf(lg[row][a] - mx); spi += q.pi[brow * A + a]; }
+        for (int o = 8; o; o >>= 1) { se += __shfl_xor(se, o, 16); spi += __shfl_xor(spi, o, 16); }
+        const float lse = mx + logf(se);
+        float lpi = 0.f;
+        for (int a = j; a < NHP; a += 16) {
+            float g = 0.f;
+            if (a < A) {
+                const float lp = lg[row][a] - lse, pit = q.pi[brow * A + a];
+                lpi = fmaf(pit, lp, lpi);
+                g = (expf(lp) * spi - pit) * invB;
+            } else if (a == A) {
+                const float vv = tanhf(lg[row][A]), zz = (float)q.z[brow];
+                g = 2.0f * (vv - zz) * (1.0f - vv * vv) * invB;
+            }
+            q.dlog[(size_t)(r0 + row) * NHP + a] = g;
+        }
+        for (int o = 8; o; o >>= 1) lpi += __shfl_xor(lpi, o, 16);
+        if (j == 0) {
+            const float vv = tanhf(lg[row][A]), zz = (float)q.z[brow];
+            rowl[row][0] = -(double)lpi; rowl[row][1] = (double)(vv - zz) * (double)(vv - zz);
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int r = 0; r < 16; ++r) { a0 += rowl[r][0]; a1 += rowl[r][1]; }
+        q.losspart[blockIdx.x * 2] = (float)a0; q.losspart[blockIdx.x * 2 + 1] = (float)a1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- BatchNorm1d backward
+// dh: LDS [B][16], the gradient w.r.t. the layer's output h = dropout(relu(bn(y))) for columns n0..n0+15.  Thread (col, row group)
+// of the first 256 threads owns rows rg, rg + 16, ...: mask (h > 0 <=> ReLU passed and the unit was kept), batch sums,
+// dz = g inv (dy - mean(dy) - xhat mean(dy xhat)), then the SGD update of the BatchNorm affine pair and of the dense bias (its gradient,
+// sum dz, is zero up to rounding).  Every thread of the workgroup must call (barriers inside).
+template <int RTM>
+AZ_D void bn1d_bwd(const TDims &d, const TPtr &q, const Hyper &hp, int layer, int n0, const float *dh, double *scr /* [16][16] */) {
+    const int B = d.B, RT = B / 16, t = threadIdx.x, col = t & 15, rg = (t >> 4) & 15, n = n0 + col, N = layer == 1 ? d.F1 : d.F2;
+    const bool act = t < 256;
+    const float *y = layer == 1 ? q.y1 : q.y2, *h = layer == 1 ? q.h1 : q.h2;
+    float *dz = layer == 1 ? q.dz1 : q.dz2;
+    const float mu = (layer == 1 ? q.mu1 : q.mu2)[n], iv = (layer == 1 ? q.iv1 : q.iv2)[n];
+    float *gam = layer == 1 ? q.p.g1 : q.p.g2, *bet = layer == 1 ? q.p.be1 : q.p.be2, *bia = layer == 1 ? q.p.b1 : q.p.b2;
+    float *mgam = layer == 1 ? q.m.g1 : q.m.g2, *mbet = layer == 1 ? q.m.be1 : q.m.be2, *mbia = layer == 1 ? q.m.b1 : q.m.b2;
+    const float keep = hp.drop_p > 0.0f ? 1.0f / (1.0f - hp.drop_p) : 1.0f;
+    float dyv[RTM], xh[RTM];
+    double s1 = 0.0, s2 = 0.0;
+    if (act) {
+        float hv[RTM], yv[RTM];
+#pragma unroll
+        for (int i = 0; i < RTM; ++i)
+            if (i < RT) { hv[i] = h[(size_t)(rg + 16 * i) * N + n]; yv[i] = y[(size_t)(rg + 16 * i) * N + n]; }
+#pragma unroll
+        for (int i = 0; i < RTM; ++i)
+            if (i < RT) {
+                dyv[i] = hv[i] > 0.0f ? dh[(rg + 16 * i) * 16 + col] * keep : 0.0f;
+                xh[i] = (yv[i] - mu) * iv;
+                s1 += dyv[i]; s2 += (double)dyv[i] * (double)xh[i];
+            }
+        scr[rg * 16 + col] = s1; scr[256 + rg * 16 + col] = s2;
+    }
+    __syncthreads();
+    double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { S1 += scr[g * 16 + col]; S2 += scr[256 + g * 16 + col]; }
+    __syncthreads();
+    if (act) {
+        const float k = gam[n] * iv, m1 = (float)(S1 / B), m2 = (float)(S2 / B);
+        double sd = 0.0;
+#pragma unroll
+        for (int i = 0; i < RTM; ++i)
+            if (i < RT) {
+                const float v = k * ((dyv[i] - m1) - xh[i] * m2);
+                dz[(size_t)(rg + 16 * i) * N + n] = v;
+                sd += v;
+            }
+        scr[rg * 16 + col] = sd;
+    }
+    __syncthreads();
+    if (act && rg == 0) {
+        double SD = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) SD += scr[g * 16 + col];
+        sgd(gam + n, mgam + n, (float)S2, hp);
+        sgd(bet + n, mbet + n, (float)S1, hp);
+        sgd(bia + n, mbia + n, (float)SD, hp);
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------- heads backward
+// 16 columns j0.. of fc2's output: d h2 = dlog Wh (K = NHP), fc_bn2 backward -> dz2, then the heads' weight gradient for the
+// same columns (dWh[a][j] = sum_b dlog[b][a] h2[b][j]) and its update: this workgroup is the only reader and writer of Wh[:, j0..]
+template <int RTM, int NT>
+__global__ __launch_bounds__(TPB) void k_heads_bwd(TDims d, TPtr q) {
+    extern __shared__ __align__(16) float lds[];
+    const int B = d.B, RT = B / 16, NHP = NT * 16, F2 = d.F2;
+    float *dh = lds;
+    double *scr = (double *)(dh + B * 16);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, j0 = blockIdx.x * 16;
+    const Hyper hp = *q.hp;
+    float wb[NT][4];  // Wh[a][j0 + n16] for the lane's rows a = 16 nt + 4 kq + i: loaded once, used by every row tile
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wb[nt][i] = q.p.wh[(size_t)(16 * nt + 4 * kq + i) * F2 + j0 + n16];
+    for (int rt = wave; rt < RT; rt += 4) {
+        float4 af[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) af[nt] = *(const float4 *)(q.dlog + (size_t)(16 * rt + n16) * NHP + 16 * nt + 4 * kq);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc = MFMA(af[nt].x, wb[nt][0], acc); acc = MFMA(af[nt].y, wb[nt][1], acc); acc = MFMA(af[nt].z, wb[nt][2], acc); acc = MFMA(af[nt].w, wb[nt][3], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[(16 * rt + 4 * kq + r) * 16 + n16] = acc[r];
+    }
+    __syncthreads();
+    bn1d_bwd<RTM>(d, q, hp, 2, j0, dh, scr);
+    for (int at = wave; at < NT; at += 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int b0 = 0; b0 < B; b0 += 32) {  // eight steps of 4 rows per trip: all loads first
+            float a[8], h[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (b0 + 4 * p < B) { a[p] = q.dlog[(size_t)(b0 + 4 * p + kq) * NHP + 16 * at + n16]; h[p] = q.h2[(size_t)(b0 + 4 * p + kq) * F2 + j0 + n16]; }
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (b0 + 4 * p < B) acc = MFMA(a[p], h[p], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 16 * at + 4 * kq + r;
+            if (a < d.NH) sgd(q.p.wh + (size_t)a * F2 + j0 + n16, q.m.wh + (size_t)a * F2 + j0 + n16, acc[r], hp);
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int a = t; a < d.NH; a += TPB) {
+            double g = 0.0;
+#pragma unroll 8
+            for (int b = 0; b < B; ++b) g += q.dlog[(size_t)b * NHP + a];
+            sgd(q.p.bh + a, q.m.bh + a, (float)g, hp);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dense data gradient
+// d h1 = dz2 W2 (the not yet updated W2) for 16 columns of fc1's output and all rows, then fc_bn1 backward
+template <int RTM, int NW, int PF>
+__global__ __launch_bounds__(NW * 64) void k_fc_dgrad(TDims d, TPtr q) {
+    extern __shared__ __align__(16) float lds[];
+    float *red = lds;
+    double *scr = (double *)(red + NW * d.B * 16 + 4 * 32);
+    const Hyper hp = *q.hp;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, RT = d.B / 16, J = d.F2;
+    const int chunk = ((J / 16 + NW - 1) / NW) * 16, jbeg = wave * chunk, jend = min(J, jbeg + chunk);
+    f32x4 acc[RTM];
+#pragma unroll
+    for (int i = 0; i < RTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    nn_kloop<RTM, PF>(acc, q.dz2, J, q.p.w2 + blockIdx.x * 16, d.F1, RT, jbeg, jend, n16, kq);
+    reduce_waves<RTM, NW>(acc, red, d.B, RT, wave, n16, kq);
+    bn1d_bwd<RTM>(d, q, hp, 1, blockIdx.x * 16, red, scr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dense weight gradient
+// dW[j][k] = sum_b dZ[b][j] X[b][k] + SGD update, one 32 x 32 tile per wave (2 x 2 MFMA tiles, K = b in steps of 4, eight steps'
+// operands loaded before their MFMAs).  layer 1: X = relu(bn4(c4)) formed on load.
+AZ_D void fc_wgrad_tile(const TDims &d, const TPtr &q, const Hyper &hp, int layer, int tile, const float *s_scale, const float *s_shift) {
+    const int lane = threadIdx.x & 63, n16 = lane & 15, kq = lane >> 4;
+    const int N = layer == 1 ? d.F1 : d.F2, K = layer == 1 ? d.FIN : d.F1, TK = K / 32;
+    if (tile >= (N / 32) * TK) return;
+    const int j0 = 32 * (tile / TK), k0 = 32 * (tile % TK);
+    const float *dZ = layer == 1 ? q.dz1 : q.dz2, *X = layer == 1 ? q.c[3] : q.h1;
+    float *W = layer == 1 ? q.p.w1 : q.p.w2, *M = layer == 1 ? q.m.w1 : q.m.w2;
+    float sc0 = 1.f, sh0 = 0.f, sc1 = 1.f, sh1 = 0.f;
+    if (layer == 1) { sc0 = s_scale[n16]; sh0 = s_shift[n16]; sc1 = s_scale[16 + n16]; sh1 = s_shift[16 + n16]; }  // k0 is a multiple of 32: channel = 16 nt + n16
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float wo[2][2][4], mo[2][2][4];  // the tile's weights and momenta: in flight under the K loop
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t idx = (size_t)(j0 + 16 * mt + 4 * kq + r) * K + k0 + 16 * nt + n16;
+                wo[mt][nt][r] = W[idx]; mo[mt][nt][r] = M[idx];
+            }
+    for (int b0 = 0; b0 < d.B; b0 += 32) {
+        float a0[8], a1[8], x0[8], x1[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (b0 + 4 * p < d.B) {
+                const float *zp = dZ + (size_t)(b0 + 4 * p + kq) * N + j0 + n16, *xp = X + (size_t)(b0 + 4 * p + kq) * K + k0 + n16;
+                a0[p] = zp[0]; a1[p] = zp[16]; x0[p] = xp[0]; x1[p] = xp[16];
+            }
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (b0 + 4 * p < d.B) {
+                float u0 = x0[p], u1 = x1[p];
+                if (layer == 1) { u0 = fmaxf(fmaf(u0, sc0, sh0), 0.f); u1 = fmaxf(fmaf(u1, sc1, sh1), 0.f); }
+                acc[0][0] = MFMA(a0[p], u0, acc[0][0]); acc[0][1] = MFMA(a0[p], u1, acc[0][1]);
+                acc[1][0] = MFMA(a1[p], u0, acc[1][0]); acc[1][1] = MFMA(a1[p], u1, acc[1][1]);
+            }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t idx = (size_t)(j0 + 16 * mt + 4 * kq + r) * K + k0 + 16 * nt + n16;
+                const float gg = fmaf(hp.wd, wo[mt][nt][r], acc[mt][nt][r]);
+                const float mm = fmaf(hp.momentum, mo[mt][nt][r], gg);
+                M[idx] = mm;
+                W[idx] = fmaf(-hp.lr, mm, wo[mt][nt][r]);
+            }
+}
+
+static inline int fc_wgrad_blocks(int N, int K, int NW) { return ((N / 32) * (K / 32) + NW - 1) / NW; }
+
+// k_mix1: [0, nw) fc2 weight gradient + update (reads dz2, h1; writes W2 -- the data gradient through W2 ran in the launch before) |
+//         [nw, nw + FIN/16) d a4 = dz1 W1 for 16 input columns (old W1), ReLU mask of a4, dy4 and the per-column sums bn4's backward needs
+template <int RTM, int NW, int PF>
+__global__ __launch_bounds__(NW * 64) void k_mix1(TDims d, TPtr q, int nw) {
+    extern __shared__ __align__(16) float lds[];
+    const Hyper hp = *q.hp;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
+    if ((int)blockIdx.x < nw) { fc_wgrad_tile(d, q, hp, 2, blockIdx.x * NW + wave, nullptr, nullptr); return; }
+    const int B = d.B, RT = B / 16, FIN = d.FIN, J = d.F1, k0 = ((int)blockIdx.x - nw) * 16;
+    float *red = lds, *s_scale = red + NW * B * 16, *s_shift = s_scale + 32, *s_mean = s_shift + 32, *s_inv = s_mean + 32;
+    double *scr = (double *)(s_inv + 32);
+    const int chunk = ((J / 16 + NW - 1) / NW) * 16, jbeg = wave * chunk, jend = min(J, jbeg + chunk);
+    f32x4 acc[RTM];
+#pragma unroll
+    for (int i = 0; i < RTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    nn_kloop<RTM, PF>(acc, q.dz1, J, q.p.w1 + k0, FIN, RT, jbeg, jend, n16, kq);  // the loads of the K loop go out before the statistics are combined
+    bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr);
+    reduce_waves<RTM, NW>(acc, red, B, RT, wave, n16, kq);
+    const int col = t & 15, rg = (t >> 4) & 15, k = k0 + col, ch = k & 31;
+    double s1 = 0.0, s2 = 0.0;
+    if (t < 256) {
+        for (int r = rg; r < B; r += 16) {
+            const float cv = q.c[3][(size_t)r * FIN + k];
+            const float v = fmaf(cv, s_scale[ch], s_shift[ch]) > 0.0f ? red[r * 16 + col] : 0.0f;
+            q.dy[3][(size_t)r * FIN + k] = v;
+            s1 += v; s2 += (double)v * (double)((cv - s_mean[ch]) * s_inv[ch]);
+        }
+        scr[rg * 16 + col] = s1; scr[256 + rg * 16 + col] = s2;
+    }
+    __syncthreads();
+    if (t < 16) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int g = 0; g < 16; ++g) { S1 += scr[g * 16 + col]; S2 += scr[256 + g * 16 + col]; }
+        q.colsum[2 * k] = S1; q.colsum[2 * k + 1] = S2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- conv backward
+// conv l (1..3 = conv2..conv4) for the boards of one workgroup.  Per board, with dz = BatchNorm backward of dy_l formed on load:
+//   data gradient   d a_{l-1}[q][ic] = sum_tap sum_oc dz[q - tap + pad][oc] W[tap][ic][oc]   (M = input positions, N = ic, K = tap x oc)
+//                   -> masked by a_{l-1} > 0 -> dy_{l-1}, and the two sums BatchNorm l-1's backward needs
+//   weight gradient dW[tap][ic][oc] += sum_p a_{l-1}[p + tap - pad][ic] dz[p][oc]                (M = ic, N = oc, K = positions), one
+//                   (ic tile, oc tile) pair per wave, nine accumulators that live across the workgroup's boards
+// LDS: wl[288][LDP] | dzp[<=100][LDP] dz with a zero halo of 2 - pad | ap[<=100][LDP] a_{l-1} with a zero halo of pad | xh[64][LDP] | dpl[64][LDP]
+#define CONV_BWD_LDS_FLOATS (288 * LDP + 100 * LDP + 100 * LDP + 64 * LDP + 64 * LDP + 11 * 32)
+#define CONV_BWD_LDS_BYTES (CONV_BWD_LDS_FLOATS * 4 + 768 * 8)
+AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblocks, float *lds) {
+    float *wl = lds, *dzp = wl + 288 * LDP, *ap = dzp + 100 * LDP, *xh = ap + 100 * LDP, *dpl = xh + 64 * LDP;
+    float *k1 = dpl + 64 * LDP, *sh_o = k1 + 32, *mean_o = sh_o + 32, *inv_o = mean_o + 32, *k2 = inv_o + 32, *k3 = k2 + 32;
+    float *sc_i = k3 + 32, *sh_i = sc_i + 32, *mean_i = sh_i + 32, *inv_i = mean_i + 32;
+    double *scr = (double *)(inv_i + 32 + 32);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, ch = t & 31, grp = t >> 5;
+    const int Hin = conv_hin(d, l), Win = conv_win(d, l), Hout = conv_hout(d, l), Wout = conv_wout(d, l), pad = l == 1 ? 1 : 0, hal = 2 - pad;
+    const int Pin = Hin * Win, Pout = Hout * Wout, WZ = Wout + 2 * hal, WA = Win + 2 * pad, MTin = (Pin + 15) / 16;
+    const int GSZ = 9 * 32 * 32 + 32;
+    TSTAMP(3, 0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int e = (i * TPB + t) * 4;
+        *(float4 *)(wl + (e >> 5) * LDP + (e & 31)) = *(const float4 *)(q.p.cw[l] + e);
+    }
+    for (int i = t; i < 200 * LDP; i += TPB) dzp[i] = 0.0f;  // dzp and ap (contiguous): the halos stay zero
+    bn2d_prepare(d, q, l, k1, sh_o, mean_o, inv_o, scr);      // k1 = gamma_l / sqrt(var_l + eps)
+    {   // mean(dy) and mean(dy xhat) of BatchNorm l over the batch: reduce the producer's partials in a fixed order
+        double S1 = 0.0, S2 = 0.0;
+        if (l == 3) {
+            for (int p = grp; p < d.P4; p += 8) { S1 += q.colsum[2 * (p * 32 + ch)]; S2 += q.colsum[2 * (p * 32 + ch) + 1]; }
+        } else {
+            for (int p = grp; p < d.NB; p += 8) { S1 += q.bpart[l][(size_t)p * 64 + ch]; S2 += q.bpart[l][(size_t)p * 64 + 32 + ch]; }
+        }
+        scr[grp * 32 + ch] = S1; scr[256 + grp * 32 + ch] = S2;
+        __syncthreads();
+        if (t < 32) {
+            S1 = 0.0; S2 = 0.0;
+            for (int g = 0; g < 8; ++g) { S1 += scr[g * 32 + ch]; S2 += scr[256 + g * 32 + ch]; }
+            const double Nn = (double)d.B * Pout;
+            k2[ch] = (float)(S1 / Nn); k3[ch] = (float)(S2 / Nn);
+        }
+        __syncthreads();
+    }
+    bn2d_prepare(d, q, l - 1, sc_i, sh_i, mean_i, inv_i, scr);
+    TSTAMP(3, 1);
+    f32x4 wacc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wmt = wave >> 1, wnt = wave & 1;
+    double s1 = 0.0, s2 = 0.0, sb = 0.0;
+    const float *dyo = q.dy[l], *co = q.c[l], *ci = q.c[l - 1];
+    float *dyi = q.dy[l - 1];
+    for (int b = bidx; b < d.B; b += nblocks) {
+        for (int i = t; i < Pout * 32; i += TPB) {
+            const int p = i >> 5, oc = i & 31;
+            const float xo = (co[(size_t)b * Pout * 32 + i] - mean_o[oc]) * inv_o[oc];
+            dzp[((p / Wout + hal) * WZ + p % Wout + hal) * LDP + oc] = k1[oc] * ((dyo[(size_t)b * Pout * 32 + i] - k2[oc]) - xo * k3[oc]);
+        }
+        for (int i = t; i < Pin * 32; i += TPB) {
+            const int p = i >> 5, ic = i & 31;
+            const float cv = ci[(size_t)b * Pin * 32 + i];
+            const float a = fmaf(cv, sc_i[ic], sh_i[ic]);
+            ap[((p / Win + pad) * WA + p % Win + pad) * LDP + ic] = a > 0.0f ? a : 0.0f;
+            xh[p * LDP + ic] = (cv - mean_i[ic]) * inv_i[ic];
+        }
+        __syncthreads();
+        TSTAMP(3, 2);
+        for (int mt = wave; mt < MTin; mt += 4) {  // data gradient
+            int m = 16 * mt + n16;
+            if (m >= Pin) m = Pin - 1;
+            const int qr = m / Win, qc = m % Win;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float *zp = dzp + ((qr - tap / 3 + pad + hal) * WZ + qc - tap % 3 + pad + hal) * LDP + kq;
+                const float *wp = wl + (tap * 32 + n16) * LDP + kq;
+#pragma unroll
+                for (int ocb = 0; ocb < 8; ++ocb) {
+                    const float a = zp[4 * ocb];
+                    acc0 = MFMA(a, wp[4 * ocb], acc0);
+                    acc1 = MFMA(a, wp[16 * LDP + 4 * ocb], acc1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mm = 16 * mt + 4 * kq + r;
+                if (mm < Pin) {
+                    const int pa = ((mm / Win + pad) * WA + mm % Win + pad) * LDP;
+                    const float v0 = ap[pa + n16] > 0.0f ? acc0[r] : 0.0f, v1 = ap[pa + 16 + n16] > 0.0f ? acc1[r] : 0.0f;
+                    dyi[((size_t)b * Pin + mm) * 32 + n16] = v0; dyi[((size_t)b * Pin + mm) * 32 + 16 + n16] = v1;
+                    dpl[mm * LDP + n16] = v0; dpl[mm * LDP + 16 + n16] = v1;
+                }
+            }
+        }
+        TSTAMP(3, 3);
+        for (int p0 = 0; p0 < Pout; p0 += 4) {  // weight gradient: K = output positions, four per MFMA
+            const int p = p0 + kq, ok = p < Pout, pr = ok ? p / Wout : 0, pc = ok ? p % Wout : 0;
+            const float bz = ok ? dzp[((pr + hal) * WZ + pc + hal) * LDP + 16 * wnt + n16] : 0.0f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                wacc[tap] = MFMA(ap[((pr + tap / 3) * WA + pc + tap % 3) * LDP + 16 * wmt + n16], bz, wacc[tap]);
+        }
+        __syncthreads();
+        TSTAMP(3, 4);
+        plane_sums(dpl, xh, Pin, s1, s2);
+        for (int p = grp; p < Pout; p += 8) sb += dzp[((p / Wout + hal) * WZ + p % Wout + hal) * LDP + ch];
+        __syncthreads();
+    }
+    TSTAMP(3, 5);
+    float *gp = q.gw[l] + (size_t)bidx * GSZ;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gp[(tap * 32 + 16 * wmt + 4 * kq + r) * 32 + 16 * wnt + n16] = wacc[tap][r];
+    scr[grp * 32 + ch] = s1; scr[256 + grp * 32 + ch] = s2; scr[512 + grp * 32 + ch] = sb;
+    __syncthreads();
+    if (t < 32) {
+        double S1 = 0.0, S2 = 0.0, SB = 0.0;
+        for (int g = 0; g < 8; ++g) { S1 += scr[g * 32 + ch]; S2 += scr[256 + g * 32 + ch]; SB += scr[512 + g * 32 + ch]; }
+        q.bpart[l - 1][(size_t)bidx * 64 + ch] = S1; q.bpart[l - 1][(size_t)bidx * 64 + 32 + ch] = S2;
+        gp[9 * 32 * 32 + ch] = (float)SB;
+    }
+    TSTAMP(3, 6);
+}
+
+__global__ __launch_bounds__(TPB) void k_conv_bwd(TDims d, TPtr q, int l) {
+    extern __shared__ __align__(16) float lds[];
+    conv_bwd_body(d, q, l, blockIdx.x, gridDim.x, lds);
+}
+
+// k_mix2: [0, nw) fc1 weight gradient + update (the data gradient through W1 ran in the launch before) | [nw, nw + NB) conv4 backward
+__global__ __launch_bounds__(TPB) void k_mix2(TDims d, TPtr q, int nw) {
+    extern __shared__ __align__(16) float lds[];
+    if ((int)blockIdx.x < nw) {
+        float *s_scale = lds, *s_shift = s_scale + 32, *s_mean = s_shift + 32, *s_inv = s_mean + 32;
+        double *scr = (double *)(s_inv + 32);
+        const Hyper hp = *q.hp;
+        bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr);
+        fc_wgrad_tile(d, q, hp, 1, blockIdx.x * 4 + (threadIdx.x >> 6), s_scale, s_shift);
+        return;
+    }
+    conv_bwd_body(d, q, 3, (int)blockIdx.x - nw, (int)gridDim.x - nw, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- conv1 backward
+// dW1[tap][oc] = sum over boards and positions of x0[p + tap - 1] dz1[p][oc] (VALU: K = 9 taps x 1 input channel); thread i owns
+// element i (and, for i < 32, element 256 + i) of the 288 + 32 partial
+__global__ __launch_bounds__(TPB) void k_conv1_bwd(TDims d, TPtr q) {
+    __shared__ float xin[10 * 10];
+    __shared__ float dzl[64 * LDP];
+    __shared__ float k1[32], sh_o[32], mean_o[32], inv_o[32], k2[32], k3[32];
+    __shared__ int poff[64];  // position -> offset of its top-left tap in the haloed input plane (no division in the inner loops)
+    __shared__ double scr[768];
+    const int t = threadIdx.x, ch = t & 31, grp = t >> 5, WP = d.CW + 2, P1 = d.P1;
+    if (t < P1) poff[t] = (t / d.CW) * WP + t % d.CW;
+    bn2d_prepare(d, q, 0, k1, sh_o, mean_o, inv_o, scr);
+    {
+        double S1 = 0.0, S2 = 0.0;
+        for (int p = grp; p < d.NB; p += 8) { S1 += q.bpart[0][(size_t)p * 64 + ch]; S2 += q.bpart[0][(size_t)p * 64 + 32 + ch]; }
+        scr[grp * 32 + ch] = S1; scr[256 + grp * 32 + ch] = S2;
+        __syncthreads();
+        if (t < 32) {
+            S1 = 0.0; S2 = 0.0;
+            for (int g = 0; g < 8; ++g) { S1 += scr[g * 32 + ch]; S2 += scr[256 + g * 32 + ch]; }
+            const double Nn = (double)d.B * P1;
+            k2[ch] = (float)(S1 / Nn); k3[ch] = (float)(S2 / Nn);
+        }
+    }
+    for (int i = t; i < 100; i += TPB) xin[i] = 0.0f;
+    __syncthreads();
+    float g0 = 0.0f, g1 = 0.0f;  // element t (tap = t >> 5, oc = t & 31) and element 256 + t (tap 8) / bias (t < 32: 288 + t handled by g1b)
+    float gb = 0.0f;
+    for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
+        for (int p = t; p < P1; p += TPB) xin[(p / d.CW + 1) * WP + p % d.CW + 1] = q.x0[(size_t)b * P1 + p];
+        for (int i = t; i < P1 * 32; i += TPB) {
+            const int oc = i & 31;
+            const float xo = (q.c[0][(size_t)b * P1 * 32 + i] - mean_o[oc]) * inv_o[oc];
+            dzl[(i >> 5) * LDP + oc] = k1[oc] * ((q.dy[0][(size_t)b * P1 * 32 + i] - k2[oc]) - xo * k3[oc]);
+        }
+        __syncthreads();
+        {
+            const int tap = t >> 5, oc = t & 31;  // taps 0..7
+            const int toff = (tap / 3) * WP + tap % 3;
+#pragma unroll 8
+            for (int p = 0; p < P1; ++p) g0 = fmaf(xin[poff[p] + toff], dzl[p * LDP + oc], g0);
+            if (t < 32) {
+#pragma unroll 8
+                for (int p = 0; p < P1; ++p) {
+                    g1 = fmaf(xin[poff[p] + 2 * WP + 2], dzl[p * LDP + oc], g1);  // tap 8
+                    gb += dzl[p * LDP + oc];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *gp = q.gw[0] + (size_t)blockIdx.x * (9 * 32 + 32);
+    gp[t] = g0;
+    if (t < 32) { gp[256 + t] = g1; gp[288 + t] = gb; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- update
+// one thread per element of conv1..4 weights / biases and of the four BatchNorm2d affine pairs: reduce the per-workgroup partials in a
+// fixed order, momentum SGD.  The last workgroup also moves the BatchNorm2d running statistics, writes the step's losses and advances
+// the step counter, the permutation offset and the loss slot.
+#define UPD_W1 288
+#define UPD_W (288 + 3 * 9216)
+#define UPD_B (UPD_W + 4 * 32)
+#define UPD_G (UPD_B + 4 * 32)
+#define UPD_ALL (UPD_G + 4 * 32)
+__global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
+    __shared__ float s_mean[32], s_var[32];
+    __shared__ double scr[768];
+    const Hyper hp = *q.hp;
+    const int t = threadIdx.x;
+    if (blockIdx.x == gridDim.x - 1) {
+        for (int l = 0; l < 4; ++l) {
+            bn2d_combine(q.fpart[l], d.NB, s_mean, s_var, scr);
+            if (t < 32) {
+                const double n = (double)d.B * plane_of(d, l);
+                q.rm[l][t] = (float)((1.0 - BN_MOM) * q.rm[l][t] + BN_MOM * s_mean[t]);
+                q.rv[l][t] = (float)((1.0 - BN_MOM) * q.rv[l][t] + BN_MOM * ((double)s_var[t] * n / (n > 1.0 ? n - 1.0 : 1.0)));
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            double a0 = 0.0, a1 = 0.0;
+            for (int i = 0; i < d.B / 16; ++i) { a0 += q.losspart[2 * i]; a1 += q.losspart[2 * i + 1]; }
+            q.loss_pi[hp.loss_off] = (float)(a0 / d.B); q.loss_v[hp.loss_off] = (float)(a1 / d.B);
+            q.hp->step = hp.step + 1; q.hp->perm_off = hp.perm_off + d.B; q.hp->loss_off = hp.loss_off + 1;
+        }
+        return;
+    }
+    const int e = blockIdx.x * TPB + t;
+    if (e >= UPD_ALL) return;
+    TSTAMP(4, 0);
+    if (e < UPD_W) {
+        const int l = e < UPD_W1 ? 0 : 1 + (e - UPD_W1) / 9216, i = e < UPD_W1 ? e : (e - UPD_W1) % 9216, sz = l == 0 ? 9 * 32 + 32 : 9 * 32 * 32 + 32;
+        float g = 0.0f;
+        const float *gp = q.gw[l] + i;
+        for (int p0 = 0; p0 < d.NB; p0 += 16) {  // sixteen partials per trip: the loads go out together, the sum keeps its order
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p0 + u < d.NB ? gp[(size_t)(p0 + u) * sz] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) g += v[u];
+        }
+        sgd(q.p.cw[l] + i, q.m.cw[l] + i, g, hp);
+        TSTAMP(4, 1);
+    } else if (e < UPD_B) {
+        const int l = (e - UPD_W) >> 5, c = (e - UPD_W) & 31, sz = l == 0 ? 9 * 32 + 32 : 9 * 32 * 32 + 32;
+        float g = 0.0f;
+#pragma unroll 8
+        for (int p = 0; p < d.NB; ++p) g += q.gw[l][(size_t)p * sz + sz - 32 + c];
+        sgd(q.p.cb[l] + c, q.m.cb[l] + c, g, hp);
+    } else {
+        const bool gam = e < UPD_G;
+        const int l = ((e - (gam ? UPD_B : UPD_G)) >> 5), c = e & 31;  // UPD_B and UPD_G are multiples of 32
+        double S = 0.0;
+        if (l == 3) { for (int p = 0; p < d.P4; ++p) S += q.colsum[2 * (p * 32 + c) + (gam ? 1 : 0)]; }
+        else {
+#pragma unroll 8
+            for (int p = 0; p < d.NB; ++p) S += q.bpart[l][(size_t)p * 64 + (gam ? 32 : 0) + c];
+        }
+        if (gam) sgd(q.p.bg[l] + c, q.m.bg[l] + c, (float)S, hp);
+        else sgd(q.p.bb[l] + c, q.m.bb[l] + c, (float)S, hp);
+    }
+}
+
+// ================================================================================================================ host side
+// torch layout <-> the step's layout.  kind 0: copy; 1: conv weight [oc][ic][3][3] <-> [tap][ic][oc] (a = input channels);
+// 2: fc1.weight [j][c * P4 + pos] <-> [j][pos * 32 + c] (a = P4).  dir 0: load (dst = ours), 1: store (dst = torch's)
+__global__ void k_relayout(float *dst, const float *src, long long n, int kind, int a, int dir) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // index in torch layout
+    if (i >= n) return;
+    long long j = i;
+    if (kind == 1) {
+        const int tap = (int)(i % 9), ic = (int)((i / 9) % a), oc = (int)(i / (9LL * a));
+        j = ((long long)tap * a + ic) * 32 + oc;
+    } else if (kind == 2) {
+        const int fin = 32 * a, k = (int)(i % fin), c = k / a, pos = k % a;
+        j = (i / fin) * fin + pos * 32 + c;
+    }
+    if (dir == 0) dst[j] = src[i]; else dst[i] = src[j];
+}
+
+struct TensorRef { float *ptr; long long numel; int kind, a; };
+
+struct az_trainer {
+    int game = 0, H = 0, W = 0, max_batch = 0;
+    TDims d;
+    TPtr q;
+    std::vector<void *> allocs;
+    std::vector<std::pair<float *, size_t>> momenta;  // zeroed by az_trainer_begin
+    std::map<std::string, TensorRef> tensors;
+    std::map<std::string, std::pair<void *, long long>> debug;  // name -> (device pointer, element count) of the workspace buffers
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipGraphExec_t graph = nullptr;
+    bool graphs_ok = true, attrs_set = false;
+    long long steps_done = 0;
+    // what the captured graph was recorded with
+    const void *g_state = nullptr, *g_pi = nullptr, *g_z = nullptr, *g_perm = nullptr, *g_lp = nullptr, *g_lv = nullptr;
+    int g_B = 0;
+};
+
+#define AZ_TRY(x) do { int _rc = (x); if (_rc != AZ_OK) return _rc; } while (0)
+
+template <typename T>
+static int talloc(az_trainer *t, T **p, size_t n) {
+    void *v = nullptr;
+    AZ_HIP(hipMalloc(&v, (n ? n : 1) * sizeof(T)));
+    AZ_HIP(hipMemset(v, 0, (n ? n : 1) * sizeof(T)));
+    t->allocs.push_back(v);
+    *p = (T *)v;
+    return AZ_OK;
+}
+
+static int palloc(az_trainer *t, float *PSet::*field, size_t n) {  // a parameter and its momentum buffer
+    AZ_TRY(talloc(t, &(t->q.p.*field), n));
+    AZ_TRY(talloc(t, &(t->q.m.*field), n));
+    t->momenta.push_back({t->q.m.*field, n});
+    return AZ_OK;
+}
+
+extern "C" int az_trainer_create(int game, int H, int W, int max_batch, az_trainer **out) {
+    AZ_REQUIRE(out, AZ_EINVAL, "null argument");
+    AZ_REQUIRE(game == AZ_OTHELLO || game == AZ_CONNECT4, AZ_EINVAL, "the hand-written training step covers OthelloNet and Connect4Net (game %d)", game);
+    AZ_REQUIRE(max_batch >= 16 && max_batch <= MAXB && max_batch % 16 == 0, AZ_EINVAL, "batch size must be a multiple of 16 in [16, %d], got %d", MAXB, max_batch);
+    TDims d;
+    memset(&d, 0, sizeof d);
+    if (game == AZ_OTHELLO) {
+        AZ_REQUIRE(H == W && H >= 6 && H <= 8 && H % 2 == 0, AZ_EINVAL, "OthelloNet training step: board 6x6 or 8x8, got %dx%d", H, W);
+        d.CH = H; d.CW = W; d.F1 = 1024; d.F2 = 512; d.A = H * W + 1;
+    } else {
+        AZ_REQUIRE(H >= 5 && H <= 8 && W >= 5 && W <= 8, AZ_EINVAL, "Connect4Net training step: board between 5x5 and 8x8, got %dx%d", W, H);
+        d.CH = W; d.CW = H; d.F1 = 64; d.F2 = 32; d.A = W;  // input.view(-1, 1, width, height) (connect4.py:399)
+    }
+    d.P1 = d.CH * d.CW; d.H3 = d.CH - 2; d.W3 = d.CW - 2; d.P3 = d.H3 * d.W3; d.H4 = d.CH - 4; d.W4 = d.CW - 4; d.P4 = d.H4 * d.W4;
+    d.FIN = 32 * d.P4; d.NH = d.A + 1; d.NHP = (d.NH + 15) / 16 * 16;
+    AZ_REQUIRE(d.NHP == 16 || d.NHP == 48 || d.NHP == 80, AZ_EINVAL, "no heads kernel for %d outputs", d.NH);
+    d.B = max_batch; d.NB = max_batch < 256 ? max_batch : 256;
+    az_trainer *t = new az_trainer();
+    t->game = game; t->H = H; t->W = W; t->max_batch = max_batch; t->d = d;
+    memset(&t->q, 0, sizeof t->q);
+    int rc = AZ_OK;
+    const size_t B = (size_t)max_batch, NBmax = 256;
+#define TA(p, n) if (rc == AZ_OK) rc = talloc(t, &t->q.p, (n))
+#define PA(f, n) if (rc == AZ_OK) rc = palloc(t, &PSet::f, (n))
+    for (int l = 0; l < 4 && rc == AZ_OK; ++l) {
+        const size_t wn = l == 0 ? 9 * 32 : 9 * 32 * 32;
+        rc = talloc(t, &t->q.p.cw[l], wn); if (rc == AZ_OK) rc = talloc(t, &t->q.m.cw[l], wn); t->momenta.push_back({t->q.m.cw[l], wn});
+        float **pp[3] = {&t->q.p.cb[l], &t->q.p.bg[l], &t->q.p.bb[l]}, **mm[3] = {&t->q.m.cb[l], &t->q.m.bg[l], &t->q.m.bb[l]};
+        for (int k = 0; k < 3 && rc == AZ_OK; ++k) { rc = talloc(t, pp[k], 32); if (rc == AZ_OK) rc = talloc(t, mm[k], 32); t->momenta.push_back({*mm[k], 32}); }
+        TA(rm[l], 32); TA(rv[l], 32);
+        const size_t P = l <= 1 ? d.P1 : (l == 2 ? d.P3 : d.P4);
+        TA(c[l], B * P * 32); TA(dy[l], B * P * 32); TA(fpart[l], NBmax * FPART);
+        TA(gw[l], NBmax * (wn + 32));
+        if (l < 3) TA(bpart[l], NBmax * 64);
+    }
+    PA(w1, (size_t)d.F1 * d.FIN); PA(b1, d.F1); PA(g1, d.F1); PA(be1, d.F1);
+    PA(w2, (size_t)d.F2 * d.F1); PA(b2, d.F2); PA(g2, d.F2); PA(be2, d.F2);
+    PA(wh, (size_t)d.NHP * d.F2); PA(bh, d.NHP);
+    TA(rm1, d.F1); TA(rv1, d.F1); TA(rm2, d.F2); TA(rv2, d.F2);
+    TA(x0, B * d.P1); TA(y1, B * d.F1); TA(h1, B * d.F1); TA(mu1, d.F1); TA(iv1, d.F1);
+    TA(y2, B * d.F2); TA(h2, B * d.F2); TA(mu2, d.F2); TA(iv2, d.F2);
+    TA(dlog, B * d.NHP); TA(losspart, (B / 16) * 2); TA(dz2, B * d.F2); TA(dz1, B * d.F1);
+    TA(colsum, (size_t)d.FIN * 2); TA(hp, 1);
+#undef TA
+#undef PA
+    if (rc == AZ_OK && (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&t->ev_out, hipEventDisableTiming) != hipSuccess)) {
+        az_set_error("could not create the trainer's stream");
+        rc = AZ_EHIP;
+    }
+    if (rc != AZ_OK) { az_trainer_destroy(t); return rc; }
+    { const char *g = getenv("AZ_TRAIN_GRAPH"); if (g && atoi(g) == 0) t->graphs_ok = false; }
+    // names as in the reference's state dict (othello.py:341-368, connect4.py:370-389)
+    auto reg = [&](const std::string &name, float *p, long long n, int kind = 0, int a = 0) { t->tensors[name] = TensorRef{p, n, kind, a}; };
+    for (int l = 0; l < 4; ++l) {
+        const std::string c = "conv" + std::to_string(l + 1), b = "bn" + std::to_string(l + 1);
+        reg(c + ".weight", t->q.p.cw[l], l == 0 ? 9 * 32 : 9 * 32 * 32, 1, l == 0 ? 1 : 32);
+        reg(c + ".bias", t->q.p.cb[l], 32);
+        reg(b + ".weight", t->q.p.bg[l], 32); reg(b + ".bias", t->q.p.bb[l], 32);
+        reg(b + ".running_mean", t->q.rm[l], 32); reg(b + ".running_var", t->q.rv[l], 32);
+    }
+    reg("fc1.weight", t->q.p.w1, (long long)d.F1 * d.FIN, 2, d.P4); reg("fc1.bias", t->q.p.b1, d.F1);
+    reg("fc_bn1.weight", t->q.p.g1, d.F1); reg("fc_bn1.bias", t->q.p.be1, d.F1); reg("fc_bn1.running_mean", t->q.rm1, d.F1); reg("fc_bn1.running_var", t->q.rv1, d.F1);
+    reg("fc2.weight", t->q.p.w2, (long long)d.F2 * d.F1); reg("fc2.bias", t->q.p.b2, d.F2);
+    reg("fc_bn2.weight", t->q.p.g2, d.F2); reg("fc_bn2.bias", t->q.p.be2, d.F2); reg("fc_bn2.running_mean", t->q.rm2, d.F2); reg("fc_bn2.running_var", t->q.rv2, d.F2);
+    reg("fc_probs.weight", t->q.p.wh, (long long)d.A * d.F2); reg("fc_probs.bias", t->q.p.bh, d.A);
+    reg("fc_value.weight", t->q.p.wh + (size_t)d.A * d.F2, d.F2); reg("fc_value.bias", t->q.p.bh + d.A, 1);
+    auto dbg = [&](const char *name, void *p, long long n) { t->debug[name] = {p, n}; };
+    for (int l = 0; l < 4; ++l) {
+        const long long P = l <= 1 ? d.P1 : (l == 2 ? d.P3 : d.P4);
+        dbg(("c" + std::to_string(l + 1)).c_str(), t->q.c[l], (long long)B * P * 32);
+        dbg(("dy" + std::to_string(l + 1)).c_str(), t->q.dy[l], (long long)B * P * 32);
+        dbg(("fpart" + std::to_string(l + 1)).c_str(), t->q.fpart[l], (long long)NBmax * FPART);
+    }
+    dbg("x0", t->q.x0, B * d.P1); dbg("y1", t->q.y1, B * d.F1); dbg("h1", t->q.h1, B * d.F1); dbg("y2", t->q.y2, B * d.F2); dbg("h2", t->q.h2, B * d.F2);
+    dbg("dlog", t->q.dlog, B * d.NHP); dbg("dz2", t->q.dz2, B * d.F2); dbg("dz1", t->q.dz1, B * d.F1); dbg("losspart", t->q.losspart, (B / 16) * 2);
+    *out = t;
+    return AZ_OK;
+}
+
+extern "C" void az_trainer_destroy(az_trainer *t) {
+    if (!t) return;
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    if (t->graph) (void)hipGraphExecDestroy(t->graph);
+    for (void *p : t->allocs) (void)hipFree(p);
+    if (t->ev_in) (void)hipEventDestroy(t->ev_in);
+    if (t->ev_out) (void)hipEventDestroy(t->ev_out);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+}
+
+// the trainer works on a stream of its own (graph capture is not allowed on the legacy default stream): ordered behind the caller's
+// stream on entry, and the caller's stream is ordered behind it on exit -- no host synchronisation
+static int t_enter(az_trainer *t, hipStream_t user) {
+    AZ_HIP(hipEventRecord(t->ev_in, user));
+    AZ_HIP(hipStreamWaitEvent(t->stream, t->ev_in, 0));
+    return AZ_OK;
+}
+static int t_leave(az_trainer *t, hipStream_t user) {
+    AZ_HIP(hipEventRecord(t->ev_out, t->stream));
+    AZ_HIP(hipStreamWaitEvent(user, t->ev_out, 0));
+    return AZ_OK;
+}
+
+static int relayout(az_trainer *t, const char *name, float *theirs, long long numel, int dir, hipStream_t user) {
+    AZ_REQUIRE(t && name && theirs, AZ_EINVAL, "null argument");
+    auto it = t->tensors.find(name);
+    AZ_REQUIRE(it != t->tensors.end(), AZ_EINVAL, "unknown tensor '%s'", name);
+    const TensorRef &r = it->second;
+    AZ_REQUIRE(numel == r.numel, AZ_EINVAL, "tensor '%s' has %lld elements, expected %lld", name, numel, r.numel);
+    AZ_TRY(t_enter(t, user));
+    const unsigned blocks = (unsigned)((numel + 255) / 256);
+    if (dir == 0) hipLaunchKernelGGL(k_relayout, dim3(blocks), dim3(256), 0, t->stream, r.ptr, (const float *)theirs, numel, r.kind, r.a, 0);
+    else hipLaunchKernelGGL(k_relayout, dim3(blocks), dim3(256), 0, t->stream, theirs, (const float *)r.ptr, numel, r.kind, r.a, 1);
+    AZ_HIP(hipGetLastError());
+    return t_leave(t, user);
+}
+
+extern "C" int az_trainer_load(az_trainer *t, const char *name, const float *d_src, int64_t numel, void *stream) {
+    return relayout(t, name, const_cast<float *>(d_src), numel, 0, (hipStream_t)stream);
+}
+
+extern "C" int az_trainer_store(az_trainer *t, const char *name, float *d_dst, int64_t numel, void *stream) {
+    return relayout(t, name, d_dst, numel, 1, (hipStream_t)stream);
+}
+
+extern "C" int az_trainer_begin(az_trainer *t, float lr, float momentum, float weight_decay, float dropout_p, uint32_t seed, void *stream) {
+    AZ_REQUIRE(t, AZ_EINVAL, "null argument");
+    AZ_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, AZ_EINVAL, "dropout probability %g outside [0, 1)", (double)dropout_p);
+    hipStream_t user = (hipStream_t)stream;
+    AZ_TRY(t_enter(t, user));
+    for (auto &m : t->momenta) AZ_HIP(hipMemsetAsync(m.first, 0, m.second * sizeof(float), t->stream));
+    Hyper h;
+    h.lr = lr; h.momentum = momentum; h.wd = weight_decay; h.drop_p = dropout_p; h.seed = seed; h.step = 0; h.perm_off = 0; h.loss_off = 0;
+    AZ_HIP(hipMemcpyAsync(t->q.hp, &h, sizeof h, hipMemcpyHostToDevice, t->stream));
+    AZ_HIP(hipStreamSynchronize(t->stream));  // h lives on this frame
+    t->steps_done = 0;
+    return t_leave(t, user);
+}
+
+extern "C" int az_trainer_set_lr(az_trainer *t, float lr, void *stream) {
+    AZ_REQUIRE(t, AZ_EINVAL, "null argument");
+    hipStream_t user = (hipStream_t)stream;
+    AZ_TRY(t_enter(t, user));
+    AZ_HIP(hipMemcpyAsync(&t->q.hp->lr, &lr, sizeof lr, hipMemcpyHostToDevice, t->stream));
+    AZ_HIP(hipStreamSynchronize(t->stream));
+    return t_leave(t, user);
+}
+
+template <int RTM, int NW, int PF, int NT>
+static int enqueue_step_t(az_trainer *t) {
+    const TDims &d = t->d;
+    const TPtr &q = t->q;
+    hipStream_t st = t->stream;
+    const int fcl = fc_lds_bytes(NW, d.B), hbl = d.B * 16 * 4 + 512 * 8;
+#define SETATTR(k, bytes) AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)))
+    if (!t->attrs_set) {
+        SETATTR(k_conv_fwd, CONV_FWD_LDS_BYTES); SETATTR(k_conv_bwd, CONV_BWD_LDS_BYTES); SETATTR(k_mix2, CONV_BWD_LDS_BYTES);
+        t->attrs_set = true;
+    }
+    {   // per instantiation: the largest batch this configuration serves (set every time: cheap, and correct across batch sizes)
+        const int fmax = fc_lds_bytes(NW, RTM * 16);
+        SETATTR((k_fc_fwd<RTM, NW, PF>), fmax); SETATTR((k_fc_dgrad<RTM, NW, PF>), fmax); SETATTR((k_mix1<RTM, NW, PF>), fmax);
+        SETATTR((k_heads_bwd<RTM, NT>), RTM * 16 * 16 * 4 + 512 * 8);
+    }
+#undef SETATTR
+    const dim3 tb(TPB), tw(NW * 64);
+    hipLaunchKernelGGL(k_conv1_fwd, dim3(d.NB), tb, 0, st, d, q);
+    for (int l = 1; l <= 3; ++l) hipLaunchKernelGGL(k_conv_fwd, dim3(d.NB), tb, CONV_FWD_LDS_BYTES, st, d, q, l);
+    hipLaunchKernelGGL((k_fc_fwd<RTM, NW, PF>), dim3(d.F1 / 16), tw, fcl, st, d, q, 1);
+    hipLaunchKernelGGL((k_fc_fwd<RTM, NW, PF>), dim3(d.F2 / 16), tw, fcl, st, d, q, 2);
+    hipLaunchKernelGGL((k_heads_fwd<NT, 8>), dim3(d.B / 16), dim3(8 * 64), 0, st, d, q);
+    hipLaunchKernelGGL((k_heads_bwd<RTM, NT>), dim3(d.F2 / 16), tb, hbl, st, d, q);
+    hipLaunchKernelGGL((k_fc_dgrad<RTM, NW, PF>), dim3(d.F1 / 16), tw, fcl, st, d, q);
+    const int nw2 = fc_wgrad_blocks(d.F2, d.F1, NW), nw1 = fc_wgrad_blocks(d.F1, d.FIN, 4);
+    hipLaunchKernelGGL((k_mix1<RTM, NW, PF>), dim3(nw2 + d.FIN / 16), tw, fcl, st, d, q, nw2);
+    hipLaunchKernelGGL(k_mix2, dim3(nw1 + d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, nw1);
+    hipLaunchKernelGGL(k_conv_bwd, dim3(d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, 2);
+    hipLaunchKernelGGL(k_conv_bwd, dim3(d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, 1);
+    hipLaunchKernelGGL(k_conv1_bwd, dim3(d.NB), tb, 0, st, d, q);
+    hipLaunchKernelGGL(k_update, dim3((UPD_ALL + TPB - 1) / TPB + 1), tb, 0, st, d, q);
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+template <int RTM, int NW, int PF>
+static int enqueue_step_r(az_trainer *t) {
+    switch (t->d.NHP) {
+        case 16: return enqueue_step_t<RTM, NW, PF, 1>(t);
+        case 48: return enqueue_step_t<RTM, NW, PF, 3>(t);
+        default: return enqueue_step_t<RTM, NW, PF, 5>(t);
+    }
+}
+
+static int enqueue_step(az_trainer *t) {  // (row tiles, waves that split K, prefetch depth) by batch size: see "dense layers: shared pieces"
+    const int RT = t->d.B / 16;
+    if (RT <= 4) return enqueue_step_r<4, 16, 2>(t);
+    if (RT <= 8) return enqueue_step_r<8, 8, 2>(t);
+    if (RT <= 16) return enqueue_step_r<16, 4, 2>(t);
+    return enqueue_step_r<32, 4, 1>(t);
+}
+
+// n_steps optimisation steps on device-resident samples: step s trains on rows d_perm[s * B .. s * B + B) of (d_state int8 [S][cells],
+// d_pi f32 [S][A], d_z int8 [S]) and writes its policy / value loss to d_loss_pi[s] / d_loss_v[s].  Asynchronous on `stream`.
+extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const float *d_pi, const int8_t *d_z, const int64_t *d_perm, int32_t n_steps,
+                                int32_t B, float *d_loss_pi, float *d_loss_v, void *stream) {
+    AZ_REQUIRE(t && d_state && d_pi && d_z && d_perm && d_loss_pi && d_loss_v, AZ_EINVAL, "null argument");
+    AZ_REQUIRE(B >= 16 && B <= t->max_batch && B % 16 == 0, AZ_EINVAL, "batch size %d: need a multiple of 16 in [16, %d]", B, t->max_batch);
+    AZ_REQUIRE(n_steps >= 0, AZ_EINVAL, "negative step count");
+    if (n_steps == 0) return AZ_OK;
+    hipStream_t user = (hipStream_t)stream;
+    AZ_TRY(t_enter(t, user));
+    const bool same = t->g_state == d_state && t->g_pi == d_pi && t->g_z == d_z && t->g_perm == d_perm && t->g_lp == d_loss_pi && t->g_lv == d_loss_v && t->g_B == B;
+    if (!same && t->graph) { (void)hipGraphExecDestroy(t->graph); t->graph = nullptr; }
+    t->d.B = B; t->d.NB = B < 256 ? B : 256;
+    t->q.state = d_state; t->q.pi = d_pi; t->q.z = d_z; t->q.perm = (const long long *)d_perm; t->q.loss_pi = d_loss_pi; t->q.loss_v = d_loss_v;
+    t->g_state = d_state; t->g_pi = d_pi; t->g_z = d_z; t->g_perm = d_perm; t->g_lp = d_loss_pi; t->g_lv = d_loss_v; t->g_B = B;
+    const int zero2[2] = {0, 0};  // perm_off, loss_off: this call's arrays start at 0 (the step counter keeps running: dropout streams)
+    AZ_HIP(hipMemcpyAsync(&t->q.hp->perm_off, zero2, sizeof zero2, hipMemcpyHostToDevice, t->stream));
+    AZ_HIP(hipStreamSynchronize(t->stream));
+    int done = 0;
+    if (t->graphs_ok && !t->graph && t->steps_done > 0) {  // the first step of a trainer runs as plain launches (kernel attributes get set)
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int rc = enqueue_step(t);
+            const hipError_t er = hipStreamEndCapture(t->stream, &g);
+            if (rc != AZ_OK || er != hipSuccess || hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                t->graph = nullptr; t->graphs_ok = false;
+            }
+            if (g) (void)hipGraphDestroy(g);
+        } else {
+            (void)hipGetLastError();
+            t->graphs_ok = false;
+        }
+    }
+    for (; done < n_steps; ++done) {
+        if (t->graph && t->steps_done > 0) AZ_HIP(hipGraphLaunch(t->graph, t->stream));
+        else {
+            AZ_TRY(enqueue_step(t));
+            if (t->graphs_ok && !t->graph && t->steps_done == 0 && done + 1 < n_steps) {  // capture now that the attributes are set
+                t->steps_done++;
+                hipGraph_t g = nullptr;
+                if (hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const int rc = enqueue_step(t);
+                    const hipError_t er = hipStreamEndCapture(t->stream, &g);
+                    if (rc != AZ_OK || er != hipSuccess || hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0) != hipSuccess) {
+                        (void)hipGetLastError();
+                        t->graph = nullptr; t->graphs_ok = false;
+                    }
+                    if (g) (void)hipGraphDestroy(g);
+                } else {
+                    (void)hipGetLastError();
+                    t->graphs_ok = false;
+                }
+                continue;
+            }
+        }
+        t->steps_done++;
+    }
+    return t_leave(t, user);
+}
+
+// test access to the workspace (activations, gradients, partials) of the LAST step
+extern "C" int az_trainer_debug(az_trainer *t, const char *name, void **d_ptr, int64_t *numel) {
+    AZ_REQUIRE(t && name && d_ptr && numel, AZ_EINVAL, "null argument");
+#ifdef AZ_TPROBE
+    if (!strcmp(name, "probe")) {
+        void *p = nullptr;
+        AZ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(az_tprobe)));
+        *d_ptr = p; *numel = 32 * 16 * 2;  // as float-sized words
+        return AZ_OK;
+    }
+#endif
+    auto it = t->debug.find(name);
+    AZ_REQUIRE(it != t->debug.end(), AZ_EINVAL, "unknown workspace buffer '%s'", name);
+    *d_ptr = it->second.first; *numel = it->second.second;
+    return AZ_OK;
+}

@@ -75,6 +75,12 @@ class AlphaZeroTrainer:
         self.materialize_memory = materialize_memory
         # replay the SGD step as a captured HIP graph when the samples are device-resident (launch-bound otherwise)
         self.graph_sgd = True
+        # "hip": the hand-written training step (csrc/az_train.hip) where it applies -- conv nets, device-resident samples, config.device
+        # "cuda", batch size a multiple of 16 up to 512; "torch": the stock PyTorch loop everywhere (the checker).  sgd_backend_used
+        # records what the last optimize_network ran on.
+        self.sgd_backend = "hip"
+        self.sgd_backend_used = None
+        self._hip_step = None
 
     def __str__(self):
         return f"{type(self).__name__}{self.game.capitalize()}" if self.game is not None else type(self).__name__
@@ -215,9 +221,44 @@ class AlphaZeroTrainer:
             return
         self._optimize_local(iter_idx)
 
+    def _optimize_hip(self, iter_idx):
+        """the reference's loop (trainer.py:320-381) on the hand-written step: per epoch one permutation, n_batches steps replayed as a
+        HIP graph, the losses read back once; ExponentialLR(0.9) between epochs; a fresh optimizer (zero momentum) per iteration"""
+        from .train_step import HipTrainStep
+        c, m, bs = self.config, self.device_memory, self.config.batch_size
+        key = (type(self.nn_twin).__name__, self.nn_twin.hip_shape(), bs)
+        if self._hip_step is None or self._hip_step[0] != key:
+            if self._hip_step is not None:
+                self._hip_step[1].close()
+            self._hip_step = (key, HipTrainStep(self.nn_twin, max_batch=bs))
+        ts = self._hip_step[1]
+        ts.load(self.nn_twin)
+        ts.begin(c.learning_rate, 0.9, 0.0001, float(self.nn_twin.dropout), seed=(self.seed * 7919 + iter_idx * 104729 + 1) & 0xFFFFFFFF)
+        self.loss_values[iter_idx] = {}
+        lr = c.learning_rate
+        state, pi, z = m["state"].contiguous(), m["pi"].contiguous(), m["z"].contiguous()
+        for epoch in range(c.epochs):
+            n_batches = self._n_samples() // bs
+            if n_batches == 0:
+                raise ValueError(f"Too few samples in the memory ({self._n_samples()}) to create a batch with batch_size = {bs}")
+            perm = self._permutation(m["z"].shape[0], m["z"].device)[: n_batches * bs].to(torch.int64).contiguous()
+            lp = torch.empty(n_batches, dtype=torch.float32, device="cuda")
+            lv = torch.empty(n_batches, dtype=torch.float32, device="cuda")
+            ts.set_lr(lr)
+            ts.steps(state, pi, z, perm, n_batches, bs, lp, lv)
+            self.loss_values[iter_idx][epoch] = {"pi": lp.cpu().tolist(), "v": lv.cpu().tolist()}
+            lr = lr * 0.9  # torch.optim.lr_scheduler.ExponentialLR(gamma=0.9) (trainer.py:327)
+        ts.store(self.nn_twin)
+
     def _optimize_local(self, iter_idx):
         self.nn_twin = self.nn.clone()
         self.nn_twin.train()
+        from . import train_step
+        if (self.sgd_backend == "hip" and self.device_memory is not None and torch.cuda.is_available()
+                and torch.device(self.config.device).type == "cuda" and train_step.supports(self.nn_twin, self.config.batch_size)):
+            self.sgd_backend_used = "hip"
+            return self._optimize_hip(iter_idx)
+        self.sgd_backend_used = "torch"
         opt = torch.optim.SGD(self.nn_twin.parameters(), lr=self.config.learning_rate, momentum=0.9, weight_decay=0.0001)
         sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
         self.loss_values[iter_idx] = {}

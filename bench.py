@@ -454,16 +454,19 @@ def run_config5(job, episodes, sims, eval_episodes=64, variants=None):
     if variants is None:
         # the reference's hyper-parameters are batch_size 64, 10 epochs (games/othello.py:34-35); ONE epoch is run here (stated), on a
         # smaller episode count for the batch-64 variant so that both variants do a comparable number of SGD steps
-        variants = [("reference_batch_64", dict(episodes=max(64, episodes // 8), batch_size=64, epochs=1)),
-                    ("batch_512", dict(episodes=episodes, batch_size=512, epochs=1))]
+        variants = [("reference_batch_64", dict(episodes=max(64, episodes // 8), batch_size=64, epochs=1), "hip"),
+                    ("batch_512", dict(episodes=episodes, batch_size=512, epochs=1), "hip"),
+                    # the same loop on the stock PyTorch step (MIOpen convolutions, replayed as a HIP graph): the checker, timed beside it
+                    ("reference_batch_64_stock_pytorch", dict(episodes=max(64, episodes // 8), batch_size=64, epochs=1), "torch")]
     base.DEFAULT_MODELS_PATH = tempfile.mkdtemp() + "/"
     out = {"workload": f"Othello 8x8 trainer loop: self-play ({sims} sims/move) + symmetry augmentation + SGD (momentum 0.9, weight decay 1e-4, "
                        f"ExponentialLR 0.9) + weight hand-off + {eval_episodes} arena games against the previous network", "n_gpus": job.world,
            "note": "iteration 0 carries one-off costs (engine creation, graph capture, MIOpen's algorithm search when the stock PyTorch step runs); "
                    "iteration 1 is the steady state", "variants": {}}
-    for name, v in variants:
+    for name, v, backend in variants:
         torch.manual_seed(0)
         tr = AlphaZeroTrainer(verbose=False, engine_slots=min(v["episodes"], 32768), seed=0, materialize_memory=False)
+        tr.sgd_backend = backend
         tr.game = "othello"
         tr.config = OthelloConfig(board_size=8, simulations=sims, episodes=v["episodes"], epochs=v["epochs"], batch_size=v["batch_size"], iterations=2,
                                   device="cuda", eval_opponent="previous", eval_episodes=eval_episodes, do_eval=True, save=False, save_checkpoints=False)
@@ -491,15 +494,21 @@ def run_config5(job, episodes, sims, eval_episodes=64, variants=None):
                         "sgd_share": phases["optimize_network"] / sum(phases.values()),
                         "last_losses": ({k: tr.loss_values[it][v["epochs"] - 1][k][-1] for k in ("pi", "v")} if job.rank == 0 else None),
                         "eval_results": res})
-        out["variants"][name] = {**v, "sgd_step": getattr(tr, "sgd_backend", "torch"), "iterations": its,
+        out["variants"][name] = {**v, "sgd_step": {"hip": "hand-written HIP step (csrc/az_train.hip)", "torch": "stock PyTorch"}[tr.sgd_backend_used or backend], "iterations": its,
                                  "games_per_sec_whole_loop": v["episodes"] / its[1]["iteration_seconds"],
                                  "examples_per_sec_whole_loop": its[1]["samples_with_twins"] / its[1]["iteration_seconds"]}
         if tr._engine is not None:
             tr._engine.close()
         if tr._hipnet is not None:
             tr._hipnet.close()
+        if tr._hip_step is not None:
+            tr._hip_step[1].close()
         del tr
         torch.cuda.empty_cache()
+    a, b = out["variants"].get("reference_batch_64"), out["variants"].get("reference_batch_64_stock_pytorch")
+    if a and b:
+        out["sgd_ms_per_step_batch_64"] = {"hand_written": a["iterations"][1]["sgd_ms_per_step"], "stock_pytorch": b["iterations"][1]["sgd_ms_per_step"],
+                                           "ratio": b["iterations"][1]["sgd_ms_per_step"] / a["iterations"][1]["sgd_ms_per_step"]}
     return out
 
 

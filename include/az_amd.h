@@ -195,6 +195,28 @@ int az_augment(int game, int H, int W, const int8_t *d_state, const float *d_pi,
                int64_t S, int8_t *d_out_state, float *d_out_pi, int8_t *d_out_z, int32_t *d_out_meta, int64_t out_capacity,
                void *stream);
 
+/* ---- training step --------------------------------------------------------------------------
+ * replaces the body of AlphaZeroTrainer.optimize_network's batch loop (trainer.py:346-366: zero_grad, forward in train
+ * mode, loss_pi + loss_v, backward, optimizer.step) and torch.optim.SGD(lr, momentum, weight_decay) (trainer.py:326) for
+ * OthelloNet / Connect4Net on device-resident samples.  Tensors travel under the reference's state-dict names and in
+ * torch's layouts (othello.py:341-368, connect4.py:370-389); DEVICE pointers throughout. */
+typedef struct az_trainer az_trainer;
+/* game AZ othello (0, H = W in {6, 8}) or connect4 (1, H x W board); max_batch: multiple of 16, <= 512 */
+int az_trainer_create(int game, int H, int W, int max_batch, az_trainer **out);
+void az_trainer_destroy(az_trainer *t);
+/* parameters and BatchNorm running statistics in (load) and out (store): name = state-dict key, numel must match */
+int az_trainer_load(az_trainer *t, const char *name, const float *d_src, int64_t numel, void *stream);
+int az_trainer_store(az_trainer *t, const char *name, float *d_dst, int64_t numel, void *stream);
+/* a fresh optimizer (momentum buffers zeroed, step counter 0): what optimize_network creates per iteration (trainer.py:326) */
+int az_trainer_begin(az_trainer *t, float lr, float momentum, float weight_decay, float dropout_p, uint32_t seed, void *stream);
+int az_trainer_set_lr(az_trainer *t, float lr, void *stream); /* ExponentialLR between epochs (trainer.py:327, 381) */
+/* n_steps steps: step s trains on rows d_perm[s*B .. s*B+B) of the sample arrays (d_state int8 [S][H*W] = grid * player,
+ * d_pi float [S][A], d_z int8 [S]) and writes its losses to d_loss_pi[s], d_loss_v[s] (trainer.py:352-353).  Asynchronous. */
+int az_trainer_steps(az_trainer *t, const int8_t *d_state, const float *d_pi, const int8_t *d_z, const int64_t *d_perm,
+                     int32_t n_steps, int32_t B, float *d_loss_pi, float *d_loss_v, void *stream);
+/* test access: device pointer and element count of a workspace buffer of the last step ("c1".."c4", "y1", "h1", "dz1", ...) */
+int az_trainer_debug(az_trainer *t, const char *name, void **d_ptr, int64_t *numel);
+
 #ifdef __cplusplus
 }
 #endif

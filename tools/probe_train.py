@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""phase stamps of the training-step kernels (library built with `make -C alphazero_amd/csrc TPROBE=1`): us between the stamps of
+workgroup 0 in the LAST launch of each stamped kernel.   python tools/probe_train.py [tag] [batch]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import check_train_step as C  # noqa: E402
+from alphazero_amd.train_step import HipTrainStep  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "othello8"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+net = C.make_net(tag).cuda()
+state, pi, z = (t.cuda() for t in C.make_samples(net, 4096))
+perm = torch.randint(0, 4096, (8 * B,), device="cuda", dtype=torch.int64)
+hip = HipTrainStep(net, max_batch=B)
+hip.load(net)
+hip.begin(0.01, 0.9, 1e-4, 0.3, seed=1)
+lp, lv = torch.zeros(8, device="cuda"), torch.zeros(8, device="cuda")
+hip.steps(state, pi, z, perm, 8, B, lp, lv)
+torch.cuda.synchronize()
+raw = hip.debug("probe").view(torch.int32).cpu().numpy().view(np.uint64).reshape(32, 16)
+names = {1: "k_conv_fwd (last = conv4)", 2: "k_fc_fwd (last = fc2)", 3: "conv_bwd_body (last = conv2)", 4: "k_update"}
+for k, nm in names.items():
+    st = raw[k]
+    n = int((st > 0).sum())
+    print(nm, " ".join(f"{(int(st[i + 1]) - int(st[i])) / 100.0:.2f}" for i in range(n - 1) if st[i + 1] >= st[i]), "us")
