@@ -46,8 +46,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef AZ_TPROBE  // diagnostic build (make TPROBE=1): wall-clock stamps (100 MHz) of workgroup 0 at the phase boundaries of every kernel
 __device__ unsigned long long az_tprobe[32 * 16];
 #define TSTAMP(k, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) az_tprobe[(k) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TBEG(id) do { if (threadIdx.x == 0) az_tprobe[(id) * 16 + 14] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TEND(id) do { __syncthreads(); if (threadIdx.x == 0) az_tprobe[(id) * 16 + 15] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define TSTAMP(k, i)
+#define TBEG(id)
+#define TEND(id)
 #endif
 
 #define NCH 32
@@ -78,7 +82,8 @@ struct PSet {         // one set of tensors in the step's own layout (parameters
 struct TDims {
     int CH, CW, P1, H3, W3, P3, H4, W4, P4, FIN, F1, F2, A, NH, NHP;
     int B;    // batch size (multiple of 16, <= MAXB)
-    int NB;   // workgroups of the per-board kernels = forward statistic partials per layer
+    int NB;   // workgroups of the per-board kernels = statistic partials per layer (<= 256)
+    int S;    // workgroups that share a board (4 up to 64 boards, 2 up to 128, else 1): position tiles / taps are dealt out among them
 };
 
 struct TPtr {
@@ -128,6 +133,42 @@ AZ_D void bn2d_combine(const float *part, int npart, float *s_mean, float *s_var
         s_mean[ch] = (float)mean; s_var[ch] = (float)(M2 / N);
     }
     __syncthreads();
+}
+
+// The same in two halves, for kernels that need several statistics at once: fpart_walk issues this thread's loads and sums (no barrier),
+// so that the walks over two or three partial arrays are in flight together; the caller stores the sums, synchronises once and lets
+// 32 threads finish every statistic.
+AZ_D void fpart_walk(const float *part, int npart, double &N, double &S, double &Q) {
+    const int t = threadIdx.x, ch = t & 31, grp = t >> 5;
+    N = 0.0; S = 0.0; Q = 0.0;
+#pragma unroll 8
+    for (int p = grp; p < npart; p += 8) {
+        const double nb = part[p * FPART], mb = part[p * FPART + 1 + ch], qb = part[p * FPART + 33 + ch];
+        N += nb; S += nb * mb; Q += qb + nb * mb * mb;
+    }
+}
+AZ_D void bsum_walk(const TDims &d, const TPtr &q, int l, double &S1, double &S2) {  // backward sums of BatchNorm2d l (0..3)
+    const int t = threadIdx.x, ch = t & 31, grp = t >> 5;
+    S1 = 0.0; S2 = 0.0;
+    if (l == 3) {
+        for (int p = grp; p < d.P4; p += 8) { S1 += q.colsum[2 * (p * 32 + ch)]; S2 += q.colsum[2 * (p * 32 + ch) + 1]; }
+    } else {
+#pragma unroll 8
+        for (int p = grp; p < d.NB; p += 8) { S1 += q.bpart[l][(size_t)p * 64 + ch]; S2 += q.bpart[l][(size_t)p * 64 + 32 + ch]; }
+    }
+}
+// finish a forward statistic from the eight group sums at scr[g * 32 * W + ch * W + o .. o + 2]: mean, 1 / sqrt(var + eps), scale, shift
+AZ_D void fpart_finish(const TDims &d, const TPtr &q, int l, const double *scr, int W, int o, float *s_scale, float *s_shift, float *s_mean, float *s_inv) {
+    const int ch = threadIdx.x;
+    double N = 0.0, S = 0.0, Q = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { N += scr[(g * 32 + ch) * W + o]; S += scr[(g * 32 + ch) * W + o + 1]; Q += scr[(g * 32 + ch) * W + o + 2]; }
+    const double mean = S / N;
+    double M2 = Q - N * mean * mean;
+    if (M2 < 0.0) M2 = 0.0;
+    const float inv = (float)(1.0 / sqrt(M2 / N + BN_EPS));
+    const float sc = q.p.bg[l][ch] * inv;
+    s_mean[ch] = (float)mean; s_inv[ch] = inv; s_scale[ch] = sc; s_shift[ch] = q.p.bb[l][ch] - (float)mean * sc;
 }
 
 // scale / shift of train-mode BatchNorm2d l (0..3) from its forward partials; also mean / 1/sqrt(var + eps)
@@ -196,6 +237,7 @@ __global__ __launch_bounds__(TPB) void k_conv1_fwd(TDims d, TPtr q) {
     __shared__ float pl[64 * LDP];
     __shared__ double scr[8 * 32];
     const int t = threadIdx.x, WP = d.CW + 2;
+    if (blockIdx.x == 0) TBEG(0);
     const Hyper hp = *q.hp;
     for (int i = t; i < 9 * 32; i += TPB) wl[i] = q.p.cw[0][i];
     if (t < 32) bl[t] = q.p.cb[0][t];
@@ -228,73 +270,105 @@ __global__ __launch_bounds__(TPB) void k_conv1_fwd(TDims d, TPtr q) {
         if (t == 0) o[0] = (float)n;
         o[1 + t] = (float)mean; o[33 + t] = (float)M2;
     }
+    if (blockIdx.x == 0) TEND(0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- conv2..4 forward
 // implicit GEMM per board: M = output positions (tiles of 16), N = 32 oc (2 tiles), K = 9 taps x 32 ic.
 // LDS: wl[288][LDP] weights (row tap*32+ic, column oc) | ain[(Hin+2 pad)(Win+2 pad)][LDP] input activation with a zero halo | pl[64][LDP]
-#define CONV_FWD_LDS_FLOATS (288 * LDP + 100 * LDP + 64 * LDP + 4 * 32)
+// | red[4 waves][16][LDP].  A board is shared by S workgroups (position tiles dealt round robin) and a tile's K by the four waves of
+// its workgroup: at 64 boards all 256 CUs work, and a layer with a single tile (conv4) no longer leaves three waves idle.
+#define CONV_FWD_LDS_FLOATS (288 * LDP + 100 * LDP + 64 * LDP + 64 * LDP + 4 * 32)
 #define CONV_FWD_LDS_BYTES (CONV_FWD_LDS_FLOATS * 4 + 8 * 32 * 3 * 8)
 __global__ __launch_bounds__(TPB) void k_conv_fwd(TDims d, TPtr q, int l /* 1..3 */) {
     extern __shared__ __align__(16) float lds[];
-    float *wl = lds, *ain = wl + 288 * LDP, *pl = ain + 100 * LDP, *s_scale = pl + 64 * LDP, *s_shift = s_scale + 32, *s_mean = s_shift + 32,
-          *s_inv = s_mean + 32;
+    float *wl = lds, *ain = wl + 288 * LDP, *pl = ain + 100 * LDP, *red = pl + 64 * LDP, *s_scale = red + 64 * LDP, *s_shift = s_scale + 32,
+          *s_mean = s_shift + 32, *s_inv = s_mean + 32;
     double *scr = (double *)(s_inv + 32);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
     const int Hin = conv_hin(d, l), Win = conv_win(d, l), Hout = conv_hout(d, l), Wout = conv_wout(d, l), pad = l == 1 ? 1 : 0;
     const int Pin = Hin * Win, Pout = Hout * Wout, WP = Win + 2 * pad, MT = (Pout + 15) / 16;
+    if (blockIdx.x == 0) TBEG(l);
     TSTAMP(1, 0);
+    const float *cin = q.c[l - 1];
+    float *cout = q.c[l];
+    float r_c[8];  // the board's input plane travels through registers: first board before anything else, the next one under the MFMAs
+    auto fetch = [&](int b) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {  // 9216 floats as 2304 float4: nine per thread, all in flight at once
+        for (int k = 0; k < 8; ++k)
+            if (t + TPB * k < Pin * 32) r_c[k] = cin[(size_t)b * Pin * 32 + t + TPB * k];
+    };
+    const int S = d.S, part = blockIdx.x % S, bfirst = blockIdx.x / S, bstride = gridDim.x / S;
+    if (bfirst < d.B) fetch(bfirst);
+    float4 wreg[9];  // 9216 floats as 2304 float4: nine per thread, all in flight at once
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wreg[i] = *(const float4 *)(q.p.cw[l] + (i * TPB + t) * 4);
+    const float bias_t = q.p.cb[l][t & 31];
+    {
+        double a0, a1, a2;
+        fpart_walk(q.fpart[l - 1], d.NB, a0, a1, a2);
+        double *o = scr + (size_t)((t >> 5) * 32 + (t & 31)) * 3;
+        o[0] = a0; o[1] = a1; o[2] = a2;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
         const int e = (i * TPB + t) * 4;
-        *(float4 *)(wl + (e >> 5) * LDP + (e & 31)) = *(const float4 *)(q.p.cw[l] + e);
+        *(float4 *)(wl + (e >> 5) * LDP + (e & 31)) = wreg[i];
     }
     for (int i = t; i < 100 * LDP; i += TPB) ain[i] = 0.0f;
     TSTAMP(1, 1);
-    bn2d_prepare(d, q, l - 1, s_scale, s_shift, s_mean, s_inv, scr);
+    __syncthreads();
+    if (t < 32) fpart_finish(d, q, l - 1, scr, 3, 0, s_scale, s_shift, s_mean, s_inv);
+    __syncthreads();
     TSTAMP(1, 2);
-    const float *cin = q.c[l - 1];
-    float *cout = q.c[l];
     double n = 0.0, mean = 0.0, M2 = 0.0;
-    for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
-        for (int i = t; i < Pin * 32; i += TPB) {
-            const int p = i >> 5, ic = i & 31;
-            const float v = fmaf(cin[(size_t)b * Pin * 32 + i], s_scale[ic], s_shift[ic]);
-            ain[((p / Win + pad) * WP + p % Win + pad) * LDP + ic] = v > 0.0f ? v : 0.0f;
+    for (int b = bfirst; b < d.B; b += bstride) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = t + TPB * k, p = i >> 5, ic = i & 31;
+            if (i < Pin * 32) {
+                const float v = fmaf(r_c[k], s_scale[ic], s_shift[ic]);
+                ain[((p / Win + pad) * WP + p % Win + pad) * LDP + ic] = v > 0.0f ? v : 0.0f;
+            }
         }
+        if (b + bstride < d.B) fetch(b + bstride);
         __syncthreads();
         TSTAMP(1, 3);
-        for (int mt = wave; mt < MT; mt += 4) {
+        int nloc = 0;  // rows of this workgroup's tiles that lie inside the plane (its tiles are mt = part, part + S, ...)
+        for (int mt = part; mt < MT; mt += S) {
             int m = 16 * mt + n16;
             if (m >= Pout) m = Pout - 1;  // rows beyond the plane compute a copy of the last position; never stored
             const int base = (m / Wout) * WP + m % Wout;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float *ap = ain + (base + (tap / 3) * WP + tap % 3) * LDP + kq;
-                const float *wp = wl + (tap * 32 + kq) * LDP + n16;
-#pragma unroll
-                for (int icb = 0; icb < 8; ++icb) {
-                    const float a = ap[icb * 4];
-                    acc0 = MFMA(a, wp[icb * 4 * LDP], acc0);
-                    acc1 = MFMA(a, wp[icb * 4 * LDP + 16], acc1);
-                }
+            for (int jj = 0; jj < 18; ++jj) {  // the tile's 72 k-steps (9 taps x 8 blocks of 4 input channels) are split over the four waves
+                const int ks = 18 * wave + jj, tap = ks >> 3, icb = ks & 7, tr = (tap * 11) >> 5, tc = tap - 3 * tr;
+                const float a = ain[(base + tr * WP + tc) * LDP + icb * 4 + kq];
+                const float *wp = wl + (tap * 32 + icb * 4 + kq) * LDP + n16;
+                acc0 = MFMA(a, wp[0], acc0);
+                acc1 = MFMA(a, wp[16], acc1);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mm = 16 * mt + 4 * kq + r;
+            for (int r = 0; r < 4; ++r) { red[(wave * 16 + 4 * kq + r) * LDP + n16] = acc0[r]; red[(wave * 16 + 4 * kq + r) * LDP + 16 + n16] = acc1[r]; }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = (t >> 5) + 8 * h, oc = t & 31, mm = 16 * mt + rr;
                 if (mm < Pout) {
-                    const float v0 = acc0[r] + q.p.cb[l][n16], v1 = acc1[r] + q.p.cb[l][16 + n16];
-                    cout[((size_t)b * Pout + mm) * 32 + n16] = v0; cout[((size_t)b * Pout + mm) * 32 + 16 + n16] = v1;
-                    pl[mm * LDP + n16] = v0; pl[mm * LDP + 16 + n16] = v1;
+                    const float v = ((red[rr * LDP + oc] + red[(16 + rr) * LDP + oc]) + (red[(32 + rr) * LDP + oc] + red[(48 + rr) * LDP + oc])) + bias_t;
+                    cout[((size_t)b * Pout + mm) * 32 + oc] = v;
+                    pl[(nloc + rr) * LDP + oc] = v;
                 }
             }
+            nloc += min(16, Pout - 16 * mt);
+            __syncthreads();
         }
-        __syncthreads();
         TSTAMP(1, 4);
-        double mb, qb;
-        plane_stats(pl, Pout, scr, mb, qb);  // ends with a barrier: the next board may overwrite ain / pl
-        chan_merge(n, mean, M2, (double)Pout, mb, qb);
+        if (nloc > 0) {
+            double mb, qb;
+            plane_stats(pl, nloc, scr, mb, qb);  // ends with a barrier: the next board may overwrite ain / pl
+            chan_merge(n, mean, M2, (double)nloc, mb, qb);
+        }
         TSTAMP(1, 5);
     }
     if (t < 32) {
@@ -302,6 +376,7 @@ __global__ __launch_bounds__(TPB) void k_conv_fwd(TDims d, TPtr q, int l /* 1..3
         if (t == 0) o[0] = (float)n;
         o[1 + t] = (float)mean; o[33 + t] = (float)M2;
     }
+    if (blockIdx.x == 0) TEND(l);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dense layers: shared pieces
@@ -309,17 +384,18 @@ __global__ __launch_bounds__(TPB) void k_conv_fwd(TDims d, TPtr q, int l /* 1..3
 // local to it; its NW waves split K, their partial sums meet in LDS.  At batch 64 every wave would otherwise walk K in a dozen
 // dependent round trips to L2 (measured: 1.2 us per 16-deep step), so (a) NW grows as the batch shrinks (16 waves at <= 64 rows), and
 // (b) a wave loads PF steps' worth of fragments before it issues their MFMAs.
-//   batch <= 64: RTM 4, NW 16, PF 2 | <= 128: 8, 8, 2 | <= 256: 16, 4, 2 | <= 512: 32, 4, 1        (red[NW][B][16] <= 128 KB)
+//   batch <= 64: RTM 4, NW 16, PF 1 | <= 128: 8, 8, 1 | <= 256: 16, 4, 1 | <= 512: 32, 4, one buffer    (red[NW][B][16] <= 128 KB)
 static inline int fc_lds_bytes(int NW, int B) { return (NW * B * 16 + 4 * 32) * 4 + 768 * 8; }
 
 // acc[rt] += A[16 rt + m][k] Bt[n][k] over k in [kbeg, kend): both operands k-contiguous, a lane loads four consecutive k as one float4
 // and feeds them to four MFMAs (the k index inside a step of 16 is 4 kq + i for A and B alike: the products pair up, only the
 // summation order differs from k ascending).  BNIN: A = relu(scale[k & 31] a + shift[k & 31]) (bn4 + ReLU formed on load).
+// Two register buffers of PF steps each: batch i + 1 is loaded before batch i is multiplied; `hook` runs right after the first
+// batch's loads have been issued (the caller's own memory work -- combining BatchNorm partials -- overlaps them).
 template <int RTM, int PF, bool BNIN>
-AZ_D void nt_kloop(f32x4 (&acc)[RTM], const float *A, int lda, const float *Brow, int RT, int kbeg, int kend, int n16, int kq,
-                   const float *s_scale, const float *s_shift) {
-    for (int k0 = kbeg; k0 < kend; k0 += 16 * PF) {
-        float4 bf[PF], af[PF][RTM];
+struct NtBatch {
+    float4 bf[PF], af[PF][RTM];
+    AZ_D void load(const float *A, int lda, const float *Brow, int RT, int k0, int kend, int n16, int kq) {
 #pragma unroll
         for (int p = 0; p < PF; ++p)
             if (k0 + 16 * p < kend) {
@@ -328,6 +404,8 @@ AZ_D void nt_kloop(f32x4 (&acc)[RTM], const float *A, int lda, const float *Brow
                 for (int rt = 0; rt < RTM; ++rt)
                     if (rt < RT) af[p][rt] = *(const float4 *)(A + (size_t)(16 * rt + n16) * lda + k0 + 16 * p + 4 * kq);
             }
+    }
+    AZ_D void mul(f32x4 (&acc)[RTM], int RT, int k0, int kend, int kq, const float *s_scale, const float *s_shift) {
 #pragma unroll
         for (int p = 0; p < PF; ++p)
             if (k0 + 16 * p < kend) {
@@ -350,14 +428,42 @@ AZ_D void nt_kloop(f32x4 (&acc)[RTM], const float *A, int lda, const float *Brow
                     }
             }
     }
+};
+
+template <int RTM, int PF, bool BNIN, typename Hook>
+AZ_D void nt_kloop(f32x4 (&acc)[RTM], const float *A, int lda, const float *Brow, int RT, int kbeg, int kend, int n16, int kq,
+                   const float *s_scale, const float *s_shift, Hook hook) {
+    if constexpr (PF == 0) {  // one step per batch, one buffer (32 row tiles: the batch alone is 132 registers)
+        NtBatch<RTM, 1, BNIN> b;
+        b.load(A, lda, Brow, RT, kbeg, kend, n16, kq);
+        hook();
+        for (int k0 = kbeg; k0 < kend; k0 += 16) {
+            b.mul(acc, RT, k0, kend, kq, s_scale, s_shift);
+            if (k0 + 16 < kend) b.load(A, lda, Brow, RT, k0 + 16, kend, n16, kq);
+        }
+        return;
+    }
+    constexpr int PFE = PF == 0 ? 1 : PF, ST = 16 * PFE;
+    NtBatch<RTM, PFE, BNIN> b0, b1;
+    b0.load(A, lda, Brow, RT, kbeg, kend, n16, kq);
+    if (kbeg + ST < kend) b1.load(A, lda, Brow, RT, kbeg + ST, kend, n16, kq);
+    hook();
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * ST) {
+        b0.mul(acc, RT, k0, kend, kq, s_scale, s_shift);
+        if (k0 + 2 * ST < kend) b0.load(A, lda, Brow, RT, k0 + 2 * ST, kend, n16, kq);
+        if (k0 + ST < kend) {
+            b1.mul(acc, RT, k0 + ST, kend, kq, s_scale, s_shift);
+            if (k0 + 3 * ST < kend) b1.load(A, lda, Brow, RT, k0 + 3 * ST, kend, n16, kq);
+        }
+    }
 }
 
 // the same with B[k][n] stored k-major (row k of W, column k0c + n): one dword per MFMA for B, float4 per four MFMAs for A = dZ
 template <int RTM, int PF>
-AZ_D void nn_kloop(f32x4 (&acc)[RTM], const float *dZ, int J, const float *W, int ldw, int RT, int jbeg, int jend, int n16, int kq) {
-    for (int j0 = jbeg; j0 < jend; j0 += 16 * PF) {
-        float bw[PF][4];
-        float4 af[PF][RTM];
+struct NnBatch {
+    float bw[PF][4];
+    float4 af[PF][RTM];
+    AZ_D void load(const float *dZ, int J, const float *W, int ldw, int RT, int j0, int jend, int n16, int kq) {
 #pragma unroll
         for (int p = 0; p < PF; ++p)
             if (j0 + 16 * p < jend) {
@@ -367,6 +473,8 @@ AZ_D void nn_kloop(f32x4 (&acc)[RTM], const float *dZ, int J, const float *W, in
                 for (int rt = 0; rt < RTM; ++rt)
                     if (rt < RT) af[p][rt] = *(const float4 *)(dZ + (size_t)(16 * rt + n16) * J + j0 + 16 * p + 4 * kq);
             }
+    }
+    AZ_D void mul(f32x4 (&acc)[RTM], int RT, int j0, int jend) {
 #pragma unroll
         for (int p = 0; p < PF; ++p)
             if (j0 + 16 * p < jend)
@@ -376,6 +484,33 @@ AZ_D void nn_kloop(f32x4 (&acc)[RTM], const float *dZ, int J, const float *W, in
                         acc[rt] = MFMA(af[p][rt].x, bw[p][0], acc[rt]); acc[rt] = MFMA(af[p][rt].y, bw[p][1], acc[rt]);
                         acc[rt] = MFMA(af[p][rt].z, bw[p][2], acc[rt]); acc[rt] = MFMA(af[p][rt].w, bw[p][3], acc[rt]);
                     }
+    }
+};
+
+template <int RTM, int PF, typename Hook>
+AZ_D void nn_kloop(f32x4 (&acc)[RTM], const float *dZ, int J, const float *W, int ldw, int RT, int jbeg, int jend, int n16, int kq, Hook hook) {
+    if constexpr (PF == 0) {
+        NnBatch<RTM, 1> b;
+        b.load(dZ, J, W, ldw, RT, jbeg, jend, n16, kq);
+        hook();
+        for (int j0 = jbeg; j0 < jend; j0 += 16) {
+            b.mul(acc, RT, j0, jend);
+            if (j0 + 16 < jend) b.load(dZ, J, W, ldw, RT, j0 + 16, jend, n16, kq);
+        }
+        return;
+    }
+    constexpr int PFE = PF == 0 ? 1 : PF, ST = 16 * PFE;
+    NnBatch<RTM, PFE> b0, b1;
+    b0.load(dZ, J, W, ldw, RT, jbeg, jend, n16, kq);
+    if (jbeg + ST < jend) b1.load(dZ, J, W, ldw, RT, jbeg + ST, jend, n16, kq);
+    hook();
+    for (int j0 = jbeg; j0 < jend; j0 += 2 * ST) {
+        b0.mul(acc, RT, j0, jend);
+        if (j0 + 2 * ST < jend) b0.load(dZ, J, W, ldw, RT, j0 + 2 * ST, jend, n16, kq);
+        if (j0 + ST < jend) {
+            b1.mul(acc, RT, j0 + ST, jend);
+            if (j0 + 3 * ST < jend) b1.load(dZ, J, W, ldw, RT, j0 + 3 * ST, jend, n16, kq);
+        }
     }
 }
 
@@ -413,21 +548,27 @@ __global__ __launch_bounds__(NW * 64) void k_fc_fwd(TDims d, TPtr q, int layer) 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
     const int N = layer == 1 ? d.F1 : d.F2, K = layer == 1 ? d.FIN : d.F1, n0 = blockIdx.x * 16;
     const float *A = layer == 1 ? q.c[3] : q.h1, *W = layer == 1 ? q.p.w1 : q.p.w2;
+    if (blockIdx.x == 0) TBEG(3 + layer);
     const Hyper hp = *q.hp;
     TSTAMP(2, 0);
-    if (layer == 1) bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr);
-    TSTAMP(2, 1);
+    const bool act = t < 256;
+    const int col = t & 15, rg = (t >> 4) & 15, n = n0 + col;
+    // what the epilogue needs from memory goes out now, under the K loop
+    const float bias = (layer == 1 ? q.p.b1 : q.p.b2)[n];
+    const float g_ = (layer == 1 ? q.p.g1 : q.p.g2)[n], b_ = (layer == 1 ? q.p.be1 : q.p.be2)[n];
+    float *rm = layer == 1 ? q.rm1 : q.rm2, *rv = layer == 1 ? q.rv1 : q.rv2;
+    const float rm_old = rm[n], rv_old = rv[n];
     const int chunk = ((K / 16 + NW - 1) / NW) * 16, kbeg = wave * chunk, kend = min(K, kbeg + chunk);
     f32x4 acc[RTM];
 #pragma unroll
     for (int i = 0; i < RTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (layer == 1) nt_kloop<RTM, PF, true>(acc, A, K, W + (size_t)(n0 + n16) * K, RT, kbeg, kend, n16, kq, s_scale, s_shift);
-    else nt_kloop<RTM, PF, false>(acc, A, K, W + (size_t)(n0 + n16) * K, RT, kbeg, kend, n16, kq, nullptr, nullptr);
+    if (layer == 1)
+        nt_kloop<RTM, PF, true>(acc, A, K, W + (size_t)(n0 + n16) * K, RT, kbeg, kend, n16, kq, s_scale, s_shift,
+                                [&] { bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr); });
+    else nt_kloop<RTM, PF, false>(acc, A, K, W + (size_t)(n0 + n16) * K, RT, kbeg, kend, n16, kq, nullptr, nullptr, [] {});
+    TSTAMP(2, 1);
     reduce_waves<RTM, NW>(acc, red, B, RT, wave, n16, kq);
     TSTAMP(2, 2);
-    const bool act = t < 256;
-    const int col = t & 15, rg = (t >> 4) & 15, n = n0 + col;
-    const float bias = (layer == 1 ? q.p.b1 : q.p.b2)[n];
     float v[RTM];
     double s = 0.0;
 #pragma unroll
@@ -451,8 +592,10 @@ __global__ __launch_bounds__(NW * 64) void k_fc_fwd(TDims d, TPtr q, int layer) 
 #pragma unroll
     for (int g = 0; g < 16; ++g) M2 += scr[g * 16 + col];
     const double var = M2 / B;
+#ifdef AZ_TPROBE
+    if (blockIdx.x == 0 && t == 0) az_tprobe[(3 + layer) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+#endif
     const float inv = (float)(1.0 / sqrt(var + BN_EPS)), mu = (float)mean;
-    const float g_ = (layer == 1 ? q.p.g1 : q.p.g2)[n], b_ = (layer == 1 ? q.p.be1 : q.p.be2)[n];
     float *y = layer == 1 ? q.y1 : q.y2, *h = layer == 1 ? q.h1 : q.h2;
 #pragma unroll
     for (int i = 0; i < RTM; ++i)
@@ -468,10 +611,12 @@ __global__ __launch_bounds__(NW * 64) void k_fc_fwd(TDims d, TPtr q, int layer) 
     if (rg == 0) {
         (layer == 1 ? q.mu1 : q.mu2)[n] = mu;
         (layer == 1 ? q.iv1 : q.iv2)[n] = inv;
-        float *rm = layer == 1 ? q.rm1 : q.rm2, *rv = layer == 1 ? q.rv1 : q.rv2;
-        rm[n] = (float)((1.0 - BN_MOM) * rm[n] + BN_MOM * mean);
-        rv[n] = (float)((1.0 - BN_MOM) * rv[n] + BN_MOM * (M2 / (B > 1 ? B - 1 : 1)));
+        rm[n] = (float)((1.0 - BN_MOM) * rm_old + BN_MOM * mean);
+        rv[n] = (float)((1.0 - BN_MOM) * rv_old + BN_MOM * (M2 / (B > 1 ? B - 1 : 1)));
     }
+#ifdef AZ_TPROBE
+    if (blockIdx.x == 0 && t == 0) az_tprobe[(3 + layer) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------- heads forward + loss
@@ -484,8 +629,16 @@ __global__ __launch_bounds__(NW * 64) void k_heads_fwd(TDims d, TPtr q) {
     __shared__ double rowl[16][2];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
     const int K = d.F2, r0 = blockIdx.x * 16, NHP = NT * 16, A = d.A;
+    if (blockIdx.x == 0) TBEG(6);
     const Hyper hp = *q.hp;
     const int chunk = ((K / 16 + NW - 1) / NW) * 16, kbeg = wave * chunk, kend = min(K, kbeg + chunk);
+    // the targets of row t >> 4 (perm -> pi, z: two dependent trips) travel under the K loop
+    const int row = (t >> 4) & 15, j = t & 15;
+    const long long brow = q.perm[hp.perm_off + r0 + row];
+    float pit[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) pit[i] = j + 16 * i < A ? q.pi[brow * A + j + 16 * i] : 0.f;
+    const float zz = (float)q.z[brow];
     f32x4 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -521,32 +674,34 @@ __global__ __launch_bounds__(NW * 64) void k_heads_fwd(TDims d, TPtr q) {
     }
     __syncthreads();
     if (t < 256) {
-        const int row = t >> 4, j = t & 15;
-        const long long brow = q.perm[hp.perm_off + r0 + row];
         const float invB = 1.0f / (float)d.B;
         float mx = -3.0e38f;
         for (int a = j; a < A; a += 16) mx = fmaxf(mx, lg[row][a]);
         for (int o = 8; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
         float se = 0.f, spi = 0.f;
-        for (int a = j; a < A; a += 16) { se += expf(lg[row][a] - mx); spi += q.pi[brow * A + a]; }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            if (j + 16 * i < A) { se += expf(lg[row][j + 16 * i] - mx); spi += pit[i]; }
         for (int o = 8; o; o >>= 1) { se += __shfl_xor(se, o, 16); spi += __shfl_xor(spi, o, 16); }
         const float lse = mx + logf(se);
         float lpi = 0.f;
-        for (int a = j; a < NHP; a += 16) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int a = j + 16 * i;
             float g = 0.f;
             if (a < A) {
-                const float lp = lg[row][a] - lse, pit = q.pi[brow * A + a];
-                lpi = fmaf(pit, lp, lpi);
-                g = (expf(lp) * spi - pit) * invB;
+                const float lp = lg[row][a] - lse;
+                lpi = fmaf(pit[i], lp, lpi);
+                g = (expf(lp) * spi - pit[i]) * invB;
             } else if (a == A) {
-                const float vv = tanhf(lg[row][A]), zz = (float)q.z[brow];
+                const float vv = tanhf(lg[row][A]);
                 g = 2.0f * (vv - zz) * (1.0f - vv * vv) * invB;
             }
             q.dlog[(size_t)(r0 + row) * NHP + a] = g;
         }
         for (int o = 8; o; o >>= 1) lpi += __shfl_xor(lpi, o, 16);
         if (j == 0) {
-            const float vv = tanhf(lg[row][A]), zz = (float)q.z[brow];
+            const float vv = tanhf(lg[row][A]);
             rowl[row][0] = -(double)lpi; rowl[row][1] = (double)(vv - zz) * (double)(vv - zz);
         }
     }
@@ -556,6 +711,7 @@ __global__ __launch_bounds__(NW * 64) void k_heads_fwd(TDims d, TPtr q) {
         for (int r = 0; r < 16; ++r) { a0 += rowl[r][0]; a1 += rowl[r][1]; }
         q.losspart[blockIdx.x * 2] = (float)a0; q.losspart[blockIdx.x * 2 + 1] = (float)a1;
     }
+    if (blockIdx.x == 0) TEND(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- BatchNorm1d backward
@@ -628,6 +784,7 @@ __global__ __launch_bounds__(TPB) void k_heads_bwd(TDims d, TPtr q) {
     float *dh = lds;
     double *scr = (double *)(dh + B * 16);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, j0 = blockIdx.x * 16;
+    if (blockIdx.x == 1) TBEG(7);
     const Hyper hp = *q.hp;
     float wb[NT][4];  // Wh[a][j0 + n16] for the lane's rows a = 16 nt + 4 kq + i: loaded once, used by every row tile
 #pragma unroll
@@ -672,6 +829,7 @@ __global__ __launch_bounds__(TPB) void k_heads_bwd(TDims d, TPtr q) {
             for (int b = 0; b < B; ++b) g += q.dlog[(size_t)b * NHP + a];
             sgd(q.p.bh + a, q.m.bh + a, (float)g, hp);
         }
+    if (blockIdx.x == 1) TEND(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dense data gradient
@@ -681,20 +839,23 @@ __global__ __launch_bounds__(NW * 64) void k_fc_dgrad(TDims d, TPtr q) {
     extern __shared__ __align__(16) float lds[];
     float *red = lds;
     double *scr = (double *)(red + NW * d.B * 16 + 4 * 32);
+    if (blockIdx.x == 0) TBEG(8);
     const Hyper hp = *q.hp;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, RT = d.B / 16, J = d.F2;
     const int chunk = ((J / 16 + NW - 1) / NW) * 16, jbeg = wave * chunk, jend = min(J, jbeg + chunk);
     f32x4 acc[RTM];
 #pragma unroll
     for (int i = 0; i < RTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    nn_kloop<RTM, PF>(acc, q.dz2, J, q.p.w2 + blockIdx.x * 16, d.F1, RT, jbeg, jend, n16, kq);
+    nn_kloop<RTM, PF>(acc, q.dz2, J, q.p.w2 + blockIdx.x * 16, d.F1, RT, jbeg, jend, n16, kq, [] {});
     reduce_waves<RTM, NW>(acc, red, d.B, RT, wave, n16, kq);
     bn1d_bwd<RTM>(d, q, hp, 1, blockIdx.x * 16, red, scr);
+    if (blockIdx.x == 0) TEND(8);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dense weight gradient
 // dW[j][k] = sum_b dZ[b][j] X[b][k] + SGD update, one 32 x 32 tile per wave (2 x 2 MFMA tiles, K = b in steps of 4, eight steps'
 // operands loaded before their MFMAs).  layer 1: X = relu(bn4(c4)) formed on load.
+template <int WB>  // steps of 4 rows whose operands are loaded before their MFMAs (4 where 16 waves share the register file, else 8)
 AZ_D void fc_wgrad_tile(const TDims &d, const TPtr &q, const Hyper &hp, int layer, int tile, const float *s_scale, const float *s_shift) {
     const int lane = threadIdx.x & 63, n16 = lane & 15, kq = lane >> 4;
     const int N = layer == 1 ? d.F1 : d.F2, K = layer == 1 ? d.FIN : d.F1, TK = K / 32;
@@ -717,16 +878,16 @@ AZ_D void fc_wgrad_tile(const TDims &d, const TPtr &q, const Hyper &hp, int laye
                 const size_t idx = (size_t)(j0 + 16 * mt + 4 * kq + r) * K + k0 + 16 * nt + n16;
                 wo[mt][nt][r] = W[idx]; mo[mt][nt][r] = M[idx];
             }
-    for (int b0 = 0; b0 < d.B; b0 += 32) {
-        float a0[8], a1[8], x0[8], x1[8];
+    for (int b0 = 0; b0 < d.B; b0 += 4 * WB) {
+        float a0[WB], a1[WB], x0[WB], x1[WB];
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
+        for (int p = 0; p < WB; ++p)
             if (b0 + 4 * p < d.B) {
                 const float *zp = dZ + (size_t)(b0 + 4 * p + kq) * N + j0 + n16, *xp = X + (size_t)(b0 + 4 * p + kq) * K + k0 + n16;
                 a0[p] = zp[0]; a1[p] = zp[16]; x0[p] = xp[0]; x1[p] = xp[16];
             }
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
+        for (int p = 0; p < WB; ++p)
             if (b0 + 4 * p < d.B) {
                 float u0 = x0[p], u1 = x1[p];
                 if (layer == 1) { u0 = fmaxf(fmaf(u0, sc0, sh0), 0.f); u1 = fmaxf(fmaf(u1, sc1, sh1), 0.f); }
@@ -757,7 +918,13 @@ __global__ __launch_bounds__(NW * 64) void k_mix1(TDims d, TPtr q, int nw) {
     extern __shared__ __align__(16) float lds[];
     const Hyper hp = *q.hp;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
-    if ((int)blockIdx.x < nw) { fc_wgrad_tile(d, q, hp, 2, blockIdx.x * NW + wave, nullptr, nullptr); return; }
+    if ((int)blockIdx.x < nw) {
+        if (blockIdx.x == 0) TBEG(9);
+        fc_wgrad_tile<(NW >= 16 ? 4 : 8)>(d, q, hp, 2, blockIdx.x * NW + wave, nullptr, nullptr);
+        if (blockIdx.x == 0) TEND(9);
+        return;
+    }
+    if ((int)blockIdx.x == nw) TBEG(10);
     const int B = d.B, RT = B / 16, FIN = d.FIN, J = d.F1, k0 = ((int)blockIdx.x - nw) * 16;
     float *red = lds, *s_scale = red + NW * B * 16, *s_shift = s_scale + 32, *s_mean = s_shift + 32, *s_inv = s_mean + 32;
     double *scr = (double *)(s_inv + 32);
@@ -765,8 +932,8 @@ __global__ __launch_bounds__(NW * 64) void k_mix1(TDims d, TPtr q, int nw) {
     f32x4 acc[RTM];
 #pragma unroll
     for (int i = 0; i < RTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    nn_kloop<RTM, PF>(acc, q.dz1, J, q.p.w1 + k0, FIN, RT, jbeg, jend, n16, kq);  // the loads of the K loop go out before the statistics are combined
-    bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr);
+    nn_kloop<RTM, PF>(acc, q.dz1, J, q.p.w1 + k0, FIN, RT, jbeg, jend, n16, kq,
+                      [&] { bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr); });  // the statistics are combined under the first loads
     reduce_waves<RTM, NW>(acc, red, B, RT, wave, n16, kq);
     const int col = t & 15, rg = (t >> 4) & 15, k = k0 + col, ch = k & 31;
     double s1 = 0.0, s2 = 0.0;
@@ -785,6 +952,7 @@ __global__ __launch_bounds__(NW * 64) void k_mix1(TDims d, TPtr q, int nw) {
         for (int g = 0; g < 16; ++g) { S1 += scr[g * 16 + col]; S2 += scr[256 + g * 16 + col]; }
         q.colsum[2 * k] = S1; q.colsum[2 * k + 1] = S2;
     }
+    if ((int)blockIdx.x == nw) TEND(10);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- conv backward
@@ -794,141 +962,169 @@ __global__ __launch_bounds__(NW * 64) void k_mix1(TDims d, TPtr q, int nw) {
 //   weight gradient dW[tap][ic][oc] += sum_p a_{l-1}[p + tap - pad][ic] dz[p][oc]                (M = ic, N = oc, K = positions), one
 //                   (ic tile, oc tile) pair per wave, nine accumulators that live across the workgroup's boards
 // LDS: wl[288][LDP] | dzp[<=100][LDP] dz with a zero halo of 2 - pad | ap[<=100][LDP] a_{l-1} with a zero halo of pad | xh[64][LDP] | dpl[64][LDP]
-#define CONV_BWD_LDS_FLOATS (288 * LDP + 100 * LDP + 100 * LDP + 64 * LDP + 64 * LDP + 11 * 32)
-#define CONV_BWD_LDS_BYTES (CONV_BWD_LDS_FLOATS * 4 + 768 * 8)
+#define CONV_BWD_LDS_FLOATS (288 * LDP + 100 * LDP + 100 * LDP + 64 * LDP + 64 * LDP + 10 * 32 + 128)
+#define CONV_BWD_LDS_BYTES (CONV_BWD_LDS_FLOATS * 4 + 2048 * 8)
 AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblocks, float *lds) {
     float *wl = lds, *dzp = wl + 288 * LDP, *ap = dzp + 100 * LDP, *xh = ap + 100 * LDP, *dpl = xh + 64 * LDP;
     float *k1 = dpl + 64 * LDP, *sh_o = k1 + 32, *mean_o = sh_o + 32, *inv_o = mean_o + 32, *k2 = inv_o + 32, *k3 = k2 + 32;
     float *sc_i = k3 + 32, *sh_i = sc_i + 32, *mean_i = sh_i + 32, *inv_i = mean_i + 32;
-    double *scr = (double *)(inv_i + 32 + 32);
+    double *scr = (double *)(inv_i + 32 + 128);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, ch = t & 31, grp = t >> 5;
     const int Hin = conv_hin(d, l), Win = conv_win(d, l), Hout = conv_hout(d, l), Wout = conv_wout(d, l), pad = l == 1 ? 1 : 0, hal = 2 - pad;
     const int Pin = Hin * Win, Pout = Hout * Wout, WZ = Wout + 2 * hal, WA = Win + 2 * pad, MTin = (Pin + 15) / 16;
     const int GSZ = 9 * 32 * 32 + 32;
     TSTAMP(3, 0);
+    const float *dyo = q.dy[l], *co = q.c[l], *ci = q.c[l - 1];
+    float *dyi = q.dy[l - 1];
+    // a board's three planes travel through registers: the first board's loads go out before anything else, the next board's while
+    // this one is being computed (<= 64 positions x 32 channels / 256 threads = 8 values per plane and thread)
+    float r_dy[8], r_co[8], r_ci[8];
+    auto fetch = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = t + TPB * k;
+            if (i < Pout * 32) { r_dy[k] = dyo[(size_t)b * Pout * 32 + i]; r_co[k] = co[(size_t)b * Pout * 32 + i]; }
+            if (i < Pin * 32) r_ci[k] = ci[(size_t)b * Pin * 32 + i];
+        }
+    };
+    const int S = d.S, part = bidx % S, bfirst = bidx / S, bstride = nblocks / S;
+    if (bfirst < d.B) fetch(bfirst);
+    float4 wreg[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wreg[i] = *(const float4 *)(q.p.cw[l] + (i * TPB + t) * 4);
+    {   // the three statistics this kernel needs, walked together: BatchNorm l (forward) and its backward sums, BatchNorm l - 1 (forward)
+        double a0, a1, a2, b0, b1, c0, c1, c2;
+        fpart_walk(q.fpart[l], d.NB, a0, a1, a2);
+        bsum_walk(d, q, l, b0, b1);
+        fpart_walk(q.fpart[l - 1], d.NB, c0, c1, c2);
+        double *o = scr + (size_t)(grp * 32 + ch) * 8;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = c0; o[6] = c1; o[7] = c2;
+    }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int e = (i * TPB + t) * 4;
-        *(float4 *)(wl + (e >> 5) * LDP + (e & 31)) = *(const float4 *)(q.p.cw[l] + e);
+        *(float4 *)(wl + (e >> 5) * LDP + (e & 31)) = wreg[i];
     }
     for (int i = t; i < 200 * LDP; i += TPB) dzp[i] = 0.0f;  // dzp and ap (contiguous): the halos stay zero
-    bn2d_prepare(d, q, l, k1, sh_o, mean_o, inv_o, scr);      // k1 = gamma_l / sqrt(var_l + eps)
-    {   // mean(dy) and mean(dy xhat) of BatchNorm l over the batch: reduce the producer's partials in a fixed order
+    int *pzo = (int *)(inv_i + 32), *pao = pzo + 64;  // output position -> offset of its cell in dzp / of its top-left tap in ap
+    if (t < Pout) { pzo[t] = ((t / Wout + hal) * WZ + t % Wout + hal) * LDP; pao[t] = ((t / Wout) * WA + t % Wout) * LDP; }
+    __syncthreads();
+    if (t < 32) {
+        fpart_finish(d, q, l, scr, 8, 0, k1, sh_o, mean_o, inv_o);      // k1 = gamma_l / sqrt(var_l + eps)
+        fpart_finish(d, q, l - 1, scr, 8, 5, sc_i, sh_i, mean_i, inv_i);
         double S1 = 0.0, S2 = 0.0;
-        if (l == 3) {
-            for (int p = grp; p < d.P4; p += 8) { S1 += q.colsum[2 * (p * 32 + ch)]; S2 += q.colsum[2 * (p * 32 + ch) + 1]; }
-        } else {
-            for (int p = grp; p < d.NB; p += 8) { S1 += q.bpart[l][(size_t)p * 64 + ch]; S2 += q.bpart[l][(size_t)p * 64 + 32 + ch]; }
-        }
-        scr[grp * 32 + ch] = S1; scr[256 + grp * 32 + ch] = S2;
-        __syncthreads();
-        if (t < 32) {
-            S1 = 0.0; S2 = 0.0;
-            for (int g = 0; g < 8; ++g) { S1 += scr[g * 32 + ch]; S2 += scr[256 + g * 32 + ch]; }
-            const double Nn = (double)d.B * Pout;
-            k2[ch] = (float)(S1 / Nn); k3[ch] = (float)(S2 / Nn);
-        }
-        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { S1 += scr[(g * 32 + ch) * 8 + 3]; S2 += scr[(g * 32 + ch) * 8 + 4]; }
+        const double Nn = (double)d.B * Pout;
+        k2[ch] = (float)(S1 / Nn); k3[ch] = (float)(S2 / Nn);
     }
-    bn2d_prepare(d, q, l - 1, sc_i, sh_i, mean_i, inv_i, scr);
+    __syncthreads();
     TSTAMP(3, 1);
     f32x4 wacc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) wacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int wmt = wave >> 1, wnt = wave & 1;
-    double s1 = 0.0, s2 = 0.0, sb = 0.0;
-    const float *dyo = q.dy[l], *co = q.c[l], *ci = q.c[l - 1];
-    float *dyi = q.dy[l - 1];
-    for (int b = bidx; b < d.B; b += nblocks) {
-        for (int i = t; i < Pout * 32; i += TPB) {
-            const int p = i >> 5, oc = i & 31;
-            const float xo = (co[(size_t)b * Pout * 32 + i] - mean_o[oc]) * inv_o[oc];
-            dzp[((p / Wout + hal) * WZ + p % Wout + hal) * LDP + oc] = k1[oc] * ((dyo[(size_t)b * Pout * 32 + i] - k2[oc]) - xo * k3[oc]);
+    double s1 = 0.0, s2 = 0.0, sb = 0.0;  // this thread's share of sum dy, sum dy xhat (channel t & 31, rows t >> 5 and + 8 of every tile) and of sum dz
+    for (int b = bfirst; b < d.B; b += bstride) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = t + TPB * k, p = i >> 5, cc = i & 31;
+            if (i < Pout * 32) {
+                const float xo = (r_co[k] - mean_o[cc]) * inv_o[cc];
+                dzp[((p / Wout + hal) * WZ + p % Wout + hal) * LDP + cc] = k1[cc] * ((r_dy[k] - k2[cc]) - xo * k3[cc]);
+            }
+            if (i < Pin * 32) {
+                const float a = fmaf(r_ci[k], sc_i[cc], sh_i[cc]);
+                ap[((p / Win + pad) * WA + p % Win + pad) * LDP + cc] = a > 0.0f ? a : 0.0f;
+                xh[p * LDP + cc] = (r_ci[k] - mean_i[cc]) * inv_i[cc];
+            }
         }
-        for (int i = t; i < Pin * 32; i += TPB) {
-            const int p = i >> 5, ic = i & 31;
-            const float cv = ci[(size_t)b * Pin * 32 + i];
-            const float a = fmaf(cv, sc_i[ic], sh_i[ic]);
-            ap[((p / Win + pad) * WA + p % Win + pad) * LDP + ic] = a > 0.0f ? a : 0.0f;
-            xh[p * LDP + ic] = (cv - mean_i[ic]) * inv_i[ic];
-        }
+        if (b + bstride < d.B) fetch(b + bstride);
         __syncthreads();
         TSTAMP(3, 2);
-        for (int mt = wave; mt < MTin; mt += 4) {  // data gradient
+        for (int mt = part; mt < MTin; mt += S) {  // data gradient: this workgroup's position tiles, a tile's 72 k-steps split over the four waves
             int m = 16 * mt + n16;
             if (m >= Pin) m = Pin - 1;
             const int qr = m / Win, qc = m % Win;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float *zp = dzp + ((qr - tap / 3 + pad + hal) * WZ + qc - tap % 3 + pad + hal) * LDP + kq;
-                const float *wp = wl + (tap * 32 + n16) * LDP + kq;
-#pragma unroll
-                for (int ocb = 0; ocb < 8; ++ocb) {
-                    const float a = zp[4 * ocb];
-                    acc0 = MFMA(a, wp[4 * ocb], acc0);
-                    acc1 = MFMA(a, wp[16 * LDP + 4 * ocb], acc1);
-                }
+            for (int jj = 0; jj < 18; ++jj) {
+                const int ks = 18 * wave + jj, tap = ks >> 3, ocb = ks & 7, tr = (tap * 11) >> 5, tc = tap - 3 * tr;
+                const float a = dzp[((qr - tr + pad + hal) * WZ + qc - tc + pad + hal) * LDP + 4 * ocb + kq];
+                const float *wp = wl + (tap * 32 + n16) * LDP + 4 * ocb + kq;
+                acc0 = MFMA(a, wp[0], acc0);
+                acc1 = MFMA(a, wp[16 * LDP], acc1);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mm = 16 * mt + 4 * kq + r;
+            for (int r = 0; r < 4; ++r) { dpl[(wave * 16 + 4 * kq + r) * LDP + n16] = acc0[r]; dpl[(wave * 16 + 4 * kq + r) * LDP + 16 + n16] = acc1[r]; }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = (t >> 5) + 8 * h, mm = 16 * mt + rr;
                 if (mm < Pin) {
-                    const int pa = ((mm / Win + pad) * WA + mm % Win + pad) * LDP;
-                    const float v0 = ap[pa + n16] > 0.0f ? acc0[r] : 0.0f, v1 = ap[pa + 16 + n16] > 0.0f ? acc1[r] : 0.0f;
-                    dyi[((size_t)b * Pin + mm) * 32 + n16] = v0; dyi[((size_t)b * Pin + mm) * 32 + 16 + n16] = v1;
-                    dpl[mm * LDP + n16] = v0; dpl[mm * LDP + 16 + n16] = v1;
+                    const float g = (dpl[rr * LDP + ch] + dpl[(16 + rr) * LDP + ch]) + (dpl[(32 + rr) * LDP + ch] + dpl[(48 + rr) * LDP + ch]);
+                    const float v = ap[((mm / Win + pad) * WA + mm % Win + pad) * LDP + ch] > 0.0f ? g : 0.0f;
+                    dyi[((size_t)b * Pin + mm) * 32 + ch] = v;
+                    s1 += v; s2 += (double)v * (double)xh[mm * LDP + ch];
                 }
             }
+            __syncthreads();
         }
         TSTAMP(3, 3);
-        for (int p0 = 0; p0 < Pout; p0 += 4) {  // weight gradient: K = output positions, four per MFMA
-            const int p = p0 + kq, ok = p < Pout, pr = ok ? p / Wout : 0, pc = ok ? p % Wout : 0;
-            const float bz = ok ? dzp[((pr + hal) * WZ + pc + hal) * LDP + 16 * wnt + n16] : 0.0f;
+#pragma unroll 4
+        for (int p0 = 0; p0 < Pout; p0 += 4) {  // weight gradient of this workgroup's taps ((tap & (S - 1)) == part): K = output positions, four per MFMA
+            const int p = p0 + kq, ok = p < Pout, oz = ok ? pzo[p] : 0, oa = ok ? pao[p] : 0;  // offsets of position p in dzp / ap (no division here)
+            const float bz = ok ? dzp[oz + 16 * wnt + n16] : 0.0f;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
-                wacc[tap] = MFMA(ap[((pr + tap / 3) * WA + pc + tap % 3) * LDP + 16 * wmt + n16], bz, wacc[tap]);
+                if ((tap & (S - 1)) == part) wacc[tap] = MFMA(ap[oa + ((tap / 3) * WA + tap % 3) * LDP + 16 * wmt + n16], bz, wacc[tap]);
         }
-        __syncthreads();
         TSTAMP(3, 4);
-        plane_sums(dpl, xh, Pin, s1, s2);
-        for (int p = grp; p < Pout; p += 8) sb += dzp[((p / Wout + hal) * WZ + p % Wout + hal) * LDP + ch];
+        if (part == 0)
+            for (int p = grp; p < Pout; p += 8) sb += dzp[((p / Wout + hal) * WZ + p % Wout + hal) * LDP + ch];
         __syncthreads();
     }
     TSTAMP(3, 5);
-    float *gp = q.gw[l] + (size_t)bidx * GSZ;
+    float *gp = q.gw[l] + (size_t)bfirst * GSZ;  // the S workgroups of a board group fill disjoint tap slices of one partial
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
+        if ((tap & (S - 1)) == part)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gp[(tap * 32 + 16 * wmt + 4 * kq + r) * 32 + 16 * wnt + n16] = wacc[tap][r];
+            for (int r = 0; r < 4; ++r) gp[(tap * 32 + 16 * wmt + 4 * kq + r) * 32 + 16 * wnt + n16] = wacc[tap][r];
     scr[grp * 32 + ch] = s1; scr[256 + grp * 32 + ch] = s2; scr[512 + grp * 32 + ch] = sb;
     __syncthreads();
     if (t < 32) {
         double S1 = 0.0, S2 = 0.0, SB = 0.0;
         for (int g = 0; g < 8; ++g) { S1 += scr[g * 32 + ch]; S2 += scr[256 + g * 32 + ch]; SB += scr[512 + g * 32 + ch]; }
         q.bpart[l - 1][(size_t)bidx * 64 + ch] = S1; q.bpart[l - 1][(size_t)bidx * 64 + 32 + ch] = S2;
-        gp[9 * 32 * 32 + ch] = (float)SB;
+        if (part == 0) gp[9 * 32 * 32 + ch] = (float)SB;
     }
     TSTAMP(3, 6);
 }
 
 __global__ __launch_bounds__(TPB) void k_conv_bwd(TDims d, TPtr q, int l) {
     extern __shared__ __align__(16) float lds[];
+    if (blockIdx.x == 0) TBEG(12 + l);
     conv_bwd_body(d, q, l, blockIdx.x, gridDim.x, lds);
+    if (blockIdx.x == 0) TEND(12 + l);
 }
 
 // k_mix2: [0, nw) fc1 weight gradient + update (the data gradient through W1 ran in the launch before) | [nw, nw + NB) conv4 backward
 __global__ __launch_bounds__(TPB) void k_mix2(TDims d, TPtr q, int nw) {
     extern __shared__ __align__(16) float lds[];
     if ((int)blockIdx.x < nw) {
+        if (blockIdx.x == 0) TBEG(11);
         float *s_scale = lds, *s_shift = s_scale + 32, *s_mean = s_shift + 32, *s_inv = s_mean + 32;
         double *scr = (double *)(s_inv + 32);
         const Hyper hp = *q.hp;
         bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr);
-        fc_wgrad_tile(d, q, hp, 1, blockIdx.x * 4 + (threadIdx.x >> 6), s_scale, s_shift);
+        fc_wgrad_tile<8>(d, q, hp, 1, blockIdx.x * 4 + (threadIdx.x >> 6), s_scale, s_shift);
+        if (blockIdx.x == 0) TEND(11);
         return;
     }
+    if ((int)blockIdx.x == nw) TBEG(12);
     conv_bwd_body(d, q, 3, (int)blockIdx.x - nw, (int)gridDim.x - nw, lds);
+    if ((int)blockIdx.x == nw) TEND(12);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- conv1 backward
@@ -941,6 +1137,7 @@ __global__ __launch_bounds__(TPB) void k_conv1_bwd(TDims d, TPtr q) {
     __shared__ int poff[64];  // position -> offset of its top-left tap in the haloed input plane (no division in the inner loops)
     __shared__ double scr[768];
     const int t = threadIdx.x, ch = t & 31, grp = t >> 5, WP = d.CW + 2, P1 = d.P1;
+    if (blockIdx.x == 0) TBEG(15);
     if (t < P1) poff[t] = (t / d.CW) * WP + t % d.CW;
     bn2d_prepare(d, q, 0, k1, sh_o, mean_o, inv_o, scr);
     {
@@ -985,6 +1182,7 @@ __global__ __launch_bounds__(TPB) void k_conv1_bwd(TDims d, TPtr q) {
     float *gp = q.gw[0] + (size_t)blockIdx.x * (9 * 32 + 32);
     gp[t] = g0;
     if (t < 32) { gp[256 + t] = g1; gp[288 + t] = gb; }
+    if (blockIdx.x == 0) TEND(15);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- update
@@ -999,6 +1197,8 @@ __global__ __launch_bounds__(TPB) void k_conv1_bwd(TDims d, TPtr q) {
 __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
     __shared__ float s_mean[32], s_var[32];
     __shared__ double scr[768];
+    if (blockIdx.x == 0) TBEG(16);
+    if (blockIdx.x == gridDim.x - 1) TBEG(17);
     const Hyper hp = *q.hp;
     const int t = threadIdx.x;
     if (blockIdx.x == gridDim.x - 1) {
@@ -1016,6 +1216,9 @@ __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
             for (int i = 0; i < d.B / 16; ++i) { a0 += q.losspart[2 * i]; a1 += q.losspart[2 * i + 1]; }
             q.loss_pi[hp.loss_off] = (float)(a0 / d.B); q.loss_v[hp.loss_off] = (float)(a1 / d.B);
             q.hp->step = hp.step + 1; q.hp->perm_off = hp.perm_off + d.B; q.hp->loss_off = hp.loss_off + 1;
+#ifdef AZ_TPROBE
+            az_tprobe[17 * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
         }
         return;
     }
@@ -1026,20 +1229,25 @@ __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
         const int l = e < UPD_W1 ? 0 : 1 + (e - UPD_W1) / 9216, i = e < UPD_W1 ? e : (e - UPD_W1) % 9216, sz = l == 0 ? 9 * 32 + 32 : 9 * 32 * 32 + 32;
         float g = 0.0f;
         const float *gp = q.gw[l] + i;
-        for (int p0 = 0; p0 < d.NB; p0 += 16) {  // sixteen partials per trip: the loads go out together, the sum keeps its order
+        const int NP = l == 0 ? d.NB : d.NB / d.S;  // conv2..4: the S workgroups that share boards fill one partial together
+        for (int p0 = 0; p0 < NP; p0 += 16) {  // sixteen partials per trip: the loads go out together, the sum keeps its order
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = p0 + u < d.NB ? gp[(size_t)(p0 + u) * sz] : 0.0f;
+            for (int u = 0; u < 16; ++u) v[u] = p0 + u < NP ? gp[(size_t)(p0 + u) * sz] : 0.0f;
 #pragma unroll
             for (int u = 0; u < 16; ++u) g += v[u];
         }
         sgd(q.p.cw[l] + i, q.m.cw[l] + i, g, hp);
         TSTAMP(4, 1);
+#ifdef AZ_TPROBE
+        if (blockIdx.x == 0 && t == 0) az_tprobe[16 * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
     } else if (e < UPD_B) {
         const int l = (e - UPD_W) >> 5, c = (e - UPD_W) & 31, sz = l == 0 ? 9 * 32 + 32 : 9 * 32 * 32 + 32;
         float g = 0.0f;
+        const int NP = l == 0 ? d.NB : d.NB / d.S;
 #pragma unroll 8
-        for (int p = 0; p < d.NB; ++p) g += q.gw[l][(size_t)p * sz + sz - 32 + c];
+        for (int p = 0; p < NP; ++p) g += q.gw[l][(size_t)p * sz + sz - 32 + c];
         sgd(q.p.cb[l] + c, q.m.cb[l] + c, g, hp);
     } else {
         const bool gam = e < UPD_G;
@@ -1084,7 +1292,8 @@ struct az_trainer {
     std::map<std::string, std::pair<void *, long long>> debug;  // name -> (device pointer, element count) of the workspace buffers
     hipStream_t stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    hipGraphExec_t graph = nullptr;
+    hipGraphExec_t graph = nullptr, graph_k = nullptr;  // one step / graph_steps consecutive steps
+    int graph_steps = 8;
     bool graphs_ok = true, attrs_set = false;
     long long steps_done = 0;
     // what the captured graph was recorded with
@@ -1127,7 +1336,7 @@ extern "C" int az_trainer_create(int game, int H, int W, int max_batch, az_train
     d.P1 = d.CH * d.CW; d.H3 = d.CH - 2; d.W3 = d.CW - 2; d.P3 = d.H3 * d.W3; d.H4 = d.CH - 4; d.W4 = d.CW - 4; d.P4 = d.H4 * d.W4;
     d.FIN = 32 * d.P4; d.NH = d.A + 1; d.NHP = (d.NH + 15) / 16 * 16;
     AZ_REQUIRE(d.NHP == 16 || d.NHP == 48 || d.NHP == 80, AZ_EINVAL, "no heads kernel for %d outputs", d.NH);
-    d.B = max_batch; d.NB = max_batch < 256 ? max_batch : 256;
+    d.B = max_batch; d.S = 1; d.NB = max_batch < 256 ? max_batch : 256;
     az_trainer *t = new az_trainer();
     t->game = game; t->H = H; t->W = W; t->max_batch = max_batch; t->d = d;
     memset(&t->q, 0, sizeof t->q);
@@ -1164,6 +1373,7 @@ extern "C" int az_trainer_create(int game, int H, int W, int max_batch, az_train
     }
     if (rc != AZ_OK) { az_trainer_destroy(t); return rc; }
     { const char *g = getenv("AZ_TRAIN_GRAPH"); if (g && atoi(g) == 0) t->graphs_ok = false; }
+    { const char *g = getenv("AZ_TRAIN_GRAPH_STEPS"); if (g && atoi(g) >= 1 && atoi(g) <= 64) t->graph_steps = atoi(g); }
     // names as in the reference's state dict (othello.py:341-368, connect4.py:370-389)
     auto reg = [&](const std::string &name, float *p, long long n, int kind = 0, int a = 0) { t->tensors[name] = TensorRef{p, n, kind, a}; };
     for (int l = 0; l < 4; ++l) {
@@ -1196,6 +1406,7 @@ extern "C" void az_trainer_destroy(az_trainer *t) {
     if (!t) return;
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     if (t->graph) (void)hipGraphExecDestroy(t->graph);
+    if (t->graph_k) (void)hipGraphExecDestroy(t->graph_k);
     for (void *p : t->allocs) (void)hipFree(p);
     if (t->ev_in) (void)hipEventDestroy(t->ev_in);
     if (t->ev_out) (void)hipEventDestroy(t->ev_out);
@@ -1308,10 +1519,10 @@ static int enqueue_step_r(az_trainer *t) {
 
 static int enqueue_step(az_trainer *t) {  // (row tiles, waves that split K, prefetch depth) by batch size: see "dense layers: shared pieces"
     const int RT = t->d.B / 16;
-    if (RT <= 4) return enqueue_step_r<4, 16, 2>(t);
-    if (RT <= 8) return enqueue_step_r<8, 8, 2>(t);
-    if (RT <= 16) return enqueue_step_r<16, 4, 2>(t);
-    return enqueue_step_r<32, 4, 1>(t);
+    if (RT <= 4) return enqueue_step_r<4, 16, 1>(t);
+    if (RT <= 8) return enqueue_step_r<8, 8, 1>(t);
+    if (RT <= 16) return enqueue_step_r<16, 4, 1>(t);
+    return enqueue_step_r<32, 4, 0>(t);
 }
 
 // n_steps optimisation steps on device-resident samples: step s trains on rows d_perm[s * B .. s * B + B) of (d_state int8 [S][cells],
@@ -1326,51 +1537,44 @@ extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const floa
     AZ_TRY(t_enter(t, user));
     const bool same = t->g_state == d_state && t->g_pi == d_pi && t->g_z == d_z && t->g_perm == d_perm && t->g_lp == d_loss_pi && t->g_lv == d_loss_v && t->g_B == B;
     if (!same && t->graph) { (void)hipGraphExecDestroy(t->graph); t->graph = nullptr; }
-    t->d.B = B; t->d.NB = B < 256 ? B : 256;
+    if (!same && t->graph_k) { (void)hipGraphExecDestroy(t->graph_k); t->graph_k = nullptr; }
+    {   // workgroups per board in the conv kernels (AZ_TRAIN_SPLIT = 1 / 2 / 4 overrides; must divide 256)
+        static int force = -1;
+        if (force < 0) { const char *e = getenv("AZ_TRAIN_SPLIT"); force = e ? atoi(e) : 0; }
+        int S = force == 1 || force == 2 || force == 4 ? force : 1;
+        while (S > 1 && B * S > 256) S >>= 1;
+        t->d.B = B; t->d.S = S; t->d.NB = B * S < 256 ? B * S : 256;
+    }
     t->q.state = d_state; t->q.pi = d_pi; t->q.z = d_z; t->q.perm = (const long long *)d_perm; t->q.loss_pi = d_loss_pi; t->q.loss_v = d_loss_v;
     t->g_state = d_state; t->g_pi = d_pi; t->g_z = d_z; t->g_perm = d_perm; t->g_lp = d_loss_pi; t->g_lv = d_loss_v; t->g_B = B;
     const int zero2[2] = {0, 0};  // perm_off, loss_off: this call's arrays start at 0 (the step counter keeps running: dropout streams)
     AZ_HIP(hipMemcpyAsync(&t->q.hp->perm_off, zero2, sizeof zero2, hipMemcpyHostToDevice, t->stream));
     AZ_HIP(hipStreamSynchronize(t->stream));
     int done = 0;
-    if (t->graphs_ok && !t->graph && t->steps_done > 0) {  // the first step of a trainer runs as plain launches (kernel attributes get set)
-        hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            const int rc = enqueue_step(t);
-            const hipError_t er = hipStreamEndCapture(t->stream, &g);
-            if (rc != AZ_OK || er != hipSuccess || hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                t->graph = nullptr; t->graphs_ok = false;
-            }
-            if (g) (void)hipGraphDestroy(g);
-        } else {
-            (void)hipGetLastError();
-            t->graphs_ok = false;
-        }
+    if (t->steps_done == 0) {  // the very first step of a trainer runs as plain launches: kernel attributes get set outside a capture
+        AZ_TRY(enqueue_step(t));
+        done = 1; t->steps_done = 1;
     }
-    for (; done < n_steps; ++done) {
-        if (t->graph && t->steps_done > 0) AZ_HIP(hipGraphLaunch(t->graph, t->stream));
-        else {
-            AZ_TRY(enqueue_step(t));
-            if (t->graphs_ok && !t->graph && t->steps_done == 0 && done + 1 < n_steps) {  // capture now that the attributes are set
-                t->steps_done++;
-                hipGraph_t g = nullptr;
-                if (hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    const int rc = enqueue_step(t);
-                    const hipError_t er = hipStreamEndCapture(t->stream, &g);
-                    if (rc != AZ_OK || er != hipSuccess || hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0) != hipSuccess) {
-                        (void)hipGetLastError();
-                        t->graph = nullptr; t->graphs_ok = false;
-                    }
-                    if (g) (void)hipGraphDestroy(g);
-                } else {
-                    (void)hipGetLastError();
-                    t->graphs_ok = false;
-                }
-                continue;
-            }
+    // Replays: one graph of graph_k consecutive steps (a graph launch costs the host ~7 us per kernel node plus a fixed part, so
+    // a 15-node graph per step would leave the host the bottleneck) and a one-step graph for the remainder.
+    auto capture = [&](int k, hipGraphExec_t *out) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); t->graphs_ok = false; return; }
+        int rc = AZ_OK;
+        for (int i = 0; i < k && rc == AZ_OK; ++i) rc = enqueue_step(t);
+        const hipError_t er = hipStreamEndCapture(t->stream, &g);
+        if (rc != AZ_OK || er != hipSuccess || hipGraphInstantiate(out, g, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            *out = nullptr; t->graphs_ok = false;
         }
-        t->steps_done++;
+        if (g) (void)hipGraphDestroy(g);
+    };
+    if (t->graphs_ok && !t->graph && n_steps - done >= 1) capture(1, &t->graph);
+    if (t->graphs_ok && !t->graph_k && t->graph_steps > 1 && n_steps - done >= t->graph_steps) capture(t->graph_steps, &t->graph_k);
+    while (done < n_steps) {
+        if (t->graph_k && n_steps - done >= t->graph_steps) { AZ_HIP(hipGraphLaunch(t->graph_k, t->stream)); done += t->graph_steps; t->steps_done += t->graph_steps; }
+        else if (t->graph) { AZ_HIP(hipGraphLaunch(t->graph, t->stream)); done++; t->steps_done++; }
+        else { AZ_TRY(enqueue_step(t)); done++; t->steps_done++; }
     }
     return t_leave(t, user);
 }

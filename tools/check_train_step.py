@@ -77,8 +77,8 @@ def report(tag="othello8", B=64, steps=3, dropout=0.0, verbose=True, seed=0):
     from alphazero_amd.train_step import HipTrainStep
     net = make_net(tag, seed)
     S = B * steps + 7
-    state, pi, z = make_samples(net, S)
-    perm = torch.randperm(S, generator=torch.Generator().manual_seed(5))[: B * steps].contiguous()
+    state, pi, z = make_samples(net, S, seed=1 + 17 * seed)
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(5 + seed))[: B * steps].contiguous()
     lr, mom, wd = 0.05, 0.9, 1e-4
     ref = copy.deepcopy(net).double().train()
     opt = torch.optim.SGD(ref.parameters(), lr=lr, momentum=mom, weight_decay=wd)
