@@ -1263,6 +1263,226 @@ __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- TicTacToeNet
+// The 316-parameter MLP of tictactoe.py:289-316 (fc1 9->9, bn1, ReLU, fc2 9->9, bn2, ReLU, fc_probs 9->9 | fc_value 9->1; no dropout):
+// one whole optimisation step -- forward, loss, backward, momentum SGD, running statistics -- in ONE launch of ONE workgroup; the
+// stock PyTorch step is ~70 launches.  Rows live in LDS ([B][12] per activation), a thread owns rows t, t + 256; batch reductions
+// (BatchNorm statistics, weight gradients) are taken in row order by the thread that owns the output element: deterministic.
+// Parameter block (torch layouts): w1[81] b1[9] g1[9] be1[9] | w2[81] b2[9] g2[9] be2[9] | wp[81] bp[9] | wv[9] bv[1]  = 316 floats.
+#define TT_W1 0
+#define TT_B1 81
+#define TT_G1 90
+#define TT_BE1 99
+#define TT_W2 108
+#define TT_B2 189
+#define TT_G2 198
+#define TT_BE2 207
+#define TT_WP 216
+#define TT_BP 297
+#define TT_WV 306
+#define TT_BV 315
+#define TT_N 316
+#define TT_LD 12
+struct TttPtr {
+    float *p, *m;         // parameters / momentum [316]
+    float *rs;            // running statistics: rm1[9] rv1[9] rm2[9] rv2[9]
+    const int8_t *state; const float *pi; const int8_t *z; const long long *perm;
+    float *loss_pi, *loss_v;
+    Hyper *hp;
+};
+
+// column statistics of act[B][TT_LD] (columns 0..8) into s_mu / s_iv; thread (col = t & 15 < 9, rg = t >> 4) partial sums, two passes
+AZ_D void ttt_colstats(const float *act, int B, float *s_mu, float *s_iv, double *s_m2, double *scr) {
+    const int t = threadIdx.x, col = t & 15, rg = t >> 4;
+    double s = 0.0;
+    if (col < 9) for (int r = rg; r < B; r += 16) s += act[r * TT_LD + col];
+    scr[rg * 16 + col] = s;
+    __syncthreads();
+    double tot = 0.0;
+    for (int g = 0; g < 16; ++g) tot += scr[g * 16 + col];
+    const double mean = tot / B;
+    __syncthreads();
+    double qq = 0.0;
+    if (col < 9) for (int r = rg; r < B; r += 16) { const double dl = act[r * TT_LD + col] - mean; qq += dl * dl; }
+    scr[rg * 16 + col] = qq;
+    __syncthreads();
+    if (t < 9) {
+        double M2 = 0.0;
+        for (int g = 0; g < 16; ++g) M2 += scr[g * 16 + t];
+        s_mu[t] = (float)mean; s_iv[t] = (float)(1.0 / sqrt(M2 / B + BN_EPS)); s_m2[t] = M2;
+    }
+    __syncthreads();
+}
+
+// BatchNorm1d backward on dh[B][TT_LD] (gradient w.r.t. relu(bn(y))): dh <- dz in place; sums for the affine pair in s_s1 / s_s2
+AZ_D void ttt_bn_bwd(float *dh, const float *y, int B, const float *s_mu, const float *s_iv, const float *gam, double *s_s1, double *s_s2, double *scr) {
+    const int t = threadIdx.x, col = t & 15, rg = t >> 4;
+    double s1 = 0.0, s2 = 0.0;
+    if (col < 9)
+        for (int r = rg; r < B; r += 16) {
+            const float xh = (y[r * TT_LD + col] - s_mu[col]) * s_iv[col];
+            const float d = dh[r * TT_LD + col];
+            s1 += d; s2 += (double)d * (double)xh;
+        }
+    scr[rg * 16 + col] = s1; scr[256 + rg * 16 + col] = s2;
+    __syncthreads();
+    if (t < 9) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int g = 0; g < 16; ++g) { S1 += scr[g * 16 + t]; S2 += scr[256 + g * 16 + t]; }
+        s_s1[t] = S1; s_s2[t] = S2;
+    }
+    __syncthreads();
+    if (col < 9) {
+        const float k = gam[col] * s_iv[col], m1 = (float)(s_s1[col] / B), m2 = (float)(s_s2[col] / B);
+        for (int r = rg; r < B; r += 16) {
+            const float xh = (y[r * TT_LD + col] - s_mu[col]) * s_iv[col];
+            dh[r * TT_LD + col] = k * ((dh[r * TT_LD + col] - m1) - xh * m2);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(TPB) void k_ttt_step(TttPtr q, int B) {
+    extern __shared__ __align__(16) float lds[];
+    float *w = lds;                         // parameters [316] (+ pad to 320)
+    float *x = w + 320, *y1 = x + B * TT_LD, *a1 = y1 + B * TT_LD, *y2 = a1 + B * TT_LD, *a2 = y2 + B * TT_LD, *dl = a2 + B * TT_LD, *d2 = dl + B * TT_LD,
+          *d1 = d2 + B * TT_LD, *gr = d1 + B * TT_LD;  // gr: gradients [320]
+    float *s_mu1 = gr + 320, *s_iv1 = s_mu1 + 16, *s_mu2 = s_iv1 + 16, *s_iv2 = s_mu2 + 16;
+    double *scr = (double *)(s_iv2 + 16), *s_m2a = scr + 512, *s_m2b = s_m2a + 16, *s_s1 = s_m2b + 16, *s_s2 = s_s1 + 16, *s_loss = s_s2 + 16;
+    const int t = threadIdx.x;
+    const Hyper hp = *q.hp;
+    for (int i = t; i < TT_N; i += TPB) w[i] = q.p[i];
+    for (int r = t; r < B; r += TPB) {
+        const long long row = q.perm[hp.perm_off + r];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x[r * TT_LD + k] = (float)q.state[row * 9 + k];
+    }
+    __syncthreads();
+    for (int r = t; r < B; r += TPB)  // fc1
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            float acc = w[TT_B1 + j];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(x[r * TT_LD + k], w[TT_W1 + j * 9 + k], acc);
+            y1[r * TT_LD + j] = acc;
+        }
+    __syncthreads();
+    ttt_colstats(y1, B, s_mu1, s_iv1, s_m2a, scr);
+    for (int r = t; r < B; r += TPB) {  // bn1 + relu, fc2
+        float a[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { a[k] = fmaxf(fmaf(w[TT_G1 + k], (y1[r * TT_LD + k] - s_mu1[k]) * s_iv1[k], w[TT_BE1 + k]), 0.f); a1[r * TT_LD + k] = a[k]; }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            float acc = w[TT_B2 + j];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(a[k], w[TT_W2 + j * 9 + k], acc);
+            y2[r * TT_LD + j] = acc;
+        }
+    }
+    __syncthreads();
+    ttt_colstats(y2, B, s_mu2, s_iv2, s_m2b, scr);
+    double lpi = 0.0, lv = 0.0;
+    const float invB = 1.0f / (float)B;
+    for (int r = t; r < B; r += TPB) {  // bn2 + relu, heads, loss, d loss / d logits
+        const long long row = q.perm[hp.perm_off + r];
+        float a[9], lg[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { a[k] = fmaxf(fmaf(w[TT_G2 + k], (y2[r * TT_LD + k] - s_mu2[k]) * s_iv2[k], w[TT_BE2 + k]), 0.f); a2[r * TT_LD + k] = a[k]; }
+        float mx = -3.0e38f, u = w[TT_BV];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            float acc = w[TT_BP + j];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(a[k], w[TT_WP + j * 9 + k], acc);
+            lg[j] = acc; mx = fmaxf(mx, acc);
+            u = fmaf(a[j], w[TT_WV + j], u);
+        }
+        float se = 0.f, spi = 0.f, pit[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { se += expf(lg[j] - mx); pit[j] = q.pi[row * 9 + j]; spi += pit[j]; }
+        const float lse = mx + logf(se);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float lp = lg[j] - lse;
+            lpi -= (double)(pit[j] * lp);
+            dl[r * TT_LD + j] = (expf(lp) * spi - pit[j]) * invB;
+        }
+        const float vv = tanhf(u), zz = (float)q.z[row];
+        lv += (double)(vv - zz) * (double)(vv - zz);
+        dl[r * TT_LD + 9] = 2.0f * (vv - zz) * (1.0f - vv * vv) * invB;
+    }
+    scr[t] = lpi; scr[256 + t] = lv;
+    __syncthreads();
+    if (t == 0) {
+        double a0 = 0.0, a1_ = 0.0;
+        for (int i = 0; i < TPB; ++i) { a0 += scr[i]; a1_ += scr[256 + i]; }
+        s_loss[0] = a0 / B; s_loss[1] = a1_ / B;
+    }
+    __syncthreads();
+    for (int r = t; r < B; r += TPB) {  // d a2 = dl [Wp; wv], masked by the ReLU
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float acc = dl[r * TT_LD + 9] * w[TT_WV + k];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) acc = fmaf(dl[r * TT_LD + j], w[TT_WP + j * 9 + k], acc);
+            d2[r * TT_LD + k] = a2[r * TT_LD + k] > 0.0f ? acc : 0.0f;
+        }
+    }
+    // heads gradients: thread e < 90 owns element (j, k) of [Wp; wv] (j = 9: the value row), threads 90..99 the biases
+    if (t < 100) {
+        double g = 0.0;
+        if (t < 90) { const int j = t / 9, k = t % 9; for (int r = 0; r < B; ++r) g += (double)(dl[r * TT_LD + j] * a2[r * TT_LD + k]); }
+        else { const int j = t - 90; for (int r = 0; r < B; ++r) g += dl[r * TT_LD + j]; }
+        gr[t < 81 ? TT_WP + t : (t < 90 ? TT_WV + (t - 81) : (t < 99 ? TT_BP + (t - 90) : TT_BV))] = (float)g;
+    }
+    __syncthreads();
+    ttt_bn_bwd(d2, y2, B, s_mu2, s_iv2, w + TT_G2, s_s1, s_s2, scr);  // d2 <- dz2
+    if (t < 9) { gr[TT_G2 + t] = (float)s_s2[t]; gr[TT_BE2 + t] = (float)s_s1[t]; }
+    for (int r = t; r < B; r += TPB) {  // d a1 = dz2 W2, masked
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) acc = fmaf(d2[r * TT_LD + j], w[TT_W2 + j * 9 + k], acc);
+            d1[r * TT_LD + k] = a1[r * TT_LD + k] > 0.0f ? acc : 0.0f;
+        }
+    }
+    if (t < 90) {  // fc2 gradients
+        double g = 0.0;
+        if (t < 81) { const int j = t / 9, k = t % 9; for (int r = 0; r < B; ++r) g += (double)(d2[r * TT_LD + j] * a1[r * TT_LD + k]); }
+        else { const int j = t - 81; for (int r = 0; r < B; ++r) g += d2[r * TT_LD + j]; }
+        gr[t < 81 ? TT_W2 + t : TT_B2 + (t - 81)] = (float)g;
+    }
+    __syncthreads();
+    ttt_bn_bwd(d1, y1, B, s_mu1, s_iv1, w + TT_G1, s_s1, s_s2, scr);  // d1 <- dz1
+    if (t < 9) { gr[TT_G1 + t] = (float)s_s2[t]; gr[TT_BE1 + t] = (float)s_s1[t]; }
+    if (t < 90) {  // fc1 gradients
+        double g = 0.0;
+        if (t < 81) { const int j = t / 9, k = t % 9; for (int r = 0; r < B; ++r) g += (double)(d1[r * TT_LD + j] * x[r * TT_LD + k]); }
+        else { const int j = t - 81; for (int r = 0; r < B; ++r) g += d1[r * TT_LD + j]; }
+        gr[t < 81 ? TT_W1 + t : TT_B1 + (t - 81)] = (float)g;
+    }
+    __syncthreads();
+    for (int i = t; i < TT_N; i += TPB) {  // momentum SGD on every parameter
+        const float gg = fmaf(hp.wd, w[i], gr[i]);
+        const float mm = fmaf(hp.momentum, q.m[i], gg);
+        q.m[i] = mm;
+        q.p[i] = fmaf(-hp.lr, mm, w[i]);
+    }
+    if (t < 9) {
+        q.rs[t] = (float)((1.0 - BN_MOM) * q.rs[t] + BN_MOM * s_mu1[t]);
+        q.rs[9 + t] = (float)((1.0 - BN_MOM) * q.rs[9 + t] + BN_MOM * (s_m2a[t] / (B > 1 ? B - 1 : 1)));
+        q.rs[18 + t] = (float)((1.0 - BN_MOM) * q.rs[18 + t] + BN_MOM * s_mu2[t]);
+        q.rs[27 + t] = (float)((1.0 - BN_MOM) * q.rs[27 + t] + BN_MOM * (s_m2b[t] / (B > 1 ? B - 1 : 1)));
+    }
+    if (t == 0) {
+        q.loss_pi[hp.loss_off] = (float)s_loss[0]; q.loss_v[hp.loss_off] = (float)s_loss[1];
+        q.hp->step = hp.step + 1; q.hp->perm_off = hp.perm_off + B; q.hp->loss_off = hp.loss_off + 1;
+    }
+}
+static inline int ttt_lds_bytes(int B) { return (320 + 8 * B * TT_LD + 320 + 64) * 4 + (512 + 16 * 5) * 8; }
+
 // ================================================================================================================ host side
 // torch layout <-> the step's layout.  kind 0: copy; 1: conv weight [oc][ic][3][3] <-> [tap][ic][oc] (a = input channels);
 // 2: fc1.weight [j][c * P4 + pos] <-> [j][pos * 32 + c] (a = P4).  dir 0: load (dst = ours), 1: store (dst = torch's)
@@ -1286,6 +1506,7 @@ struct az_trainer {
     int game = 0, H = 0, W = 0, max_batch = 0;
     TDims d;
     TPtr q;
+    TttPtr tq;  // game == AZ_TICTACTOE: the whole step is one launch (k_ttt_step)
     std::vector<void *> allocs;
     std::vector<std::pair<float *, size_t>> momenta;  // zeroed by az_trainer_begin
     std::map<std::string, TensorRef> tensors;
@@ -1322,7 +1543,35 @@ static int palloc(az_trainer *t, float *PSet::*field, size_t n) {  // a paramete
 
 extern "C" int az_trainer_create(int game, int H, int W, int max_batch, az_trainer **out) {
     AZ_REQUIRE(out, AZ_EINVAL, "null argument");
-    AZ_REQUIRE(game == AZ_OTHELLO || game == AZ_CONNECT4, AZ_EINVAL, "the hand-written training step covers OthelloNet and Connect4Net (game %d)", game);
+    AZ_REQUIRE(game == AZ_OTHELLO || game == AZ_CONNECT4 || game == AZ_TICTACTOE, AZ_EINVAL, "unknown game %d", game);
+    if (game == AZ_TICTACTOE) {
+        AZ_REQUIRE(H == 3 && W == 3, AZ_EINVAL, "TicTacToe board is 3x3");
+        AZ_REQUIRE(max_batch >= 2 && max_batch <= 256, AZ_EINVAL, "TicTacToeNet training step: batch size in [2, 256], got %d", max_batch);
+        az_trainer *t = new az_trainer();
+        t->game = game; t->H = H; t->W = W; t->max_batch = max_batch;
+        memset(&t->d, 0, sizeof t->d); memset(&t->q, 0, sizeof t->q); memset(&t->tq, 0, sizeof t->tq);
+        t->d.B = max_batch;
+        int rc = talloc(t, &t->tq.p, 320);
+        if (rc == AZ_OK) rc = talloc(t, &t->tq.m, 320);
+        if (rc == AZ_OK) rc = talloc(t, &t->tq.rs, 36);
+        if (rc == AZ_OK) rc = talloc(t, &t->tq.hp, 1);
+        if (rc == AZ_OK && (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess ||
+                            hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&t->ev_out, hipEventDisableTiming) != hipSuccess)) { az_set_error("could not create the trainer's stream"); rc = AZ_EHIP; }
+        if (rc != AZ_OK) { az_trainer_destroy(t); return rc; }
+        t->q.hp = t->tq.hp;
+        t->momenta.push_back({t->tq.m, 320});
+        { const char *g = getenv("AZ_TRAIN_GRAPH"); if (g && atoi(g) == 0) t->graphs_ok = false; }
+        { const char *g = getenv("AZ_TRAIN_GRAPH_STEPS"); if (g && atoi(g) >= 1 && atoi(g) <= 64) t->graph_steps = atoi(g); }
+        auto reg = [&](const char *name, float *p, long long n) { t->tensors[name] = TensorRef{p, n, 0, 0}; };
+        float *P = t->tq.p, *R = t->tq.rs;  // state-dict names of tictactoe.py:296-306
+        reg("fc1.weight", P + TT_W1, 81); reg("fc1.bias", P + TT_B1, 9); reg("bn1.weight", P + TT_G1, 9); reg("bn1.bias", P + TT_BE1, 9);
+        reg("fc2.weight", P + TT_W2, 81); reg("fc2.bias", P + TT_B2, 9); reg("bn2.weight", P + TT_G2, 9); reg("bn2.bias", P + TT_BE2, 9);
+        reg("fc_probs.weight", P + TT_WP, 81); reg("fc_probs.bias", P + TT_BP, 9); reg("fc_value.weight", P + TT_WV, 9); reg("fc_value.bias", P + TT_BV, 1);
+        reg("bn1.running_mean", R, 9); reg("bn1.running_var", R + 9, 9); reg("bn2.running_mean", R + 18, 9); reg("bn2.running_var", R + 27, 9);
+        *out = t;
+        return AZ_OK;
+    }
     AZ_REQUIRE(max_batch >= 16 && max_batch <= MAXB && max_batch % 16 == 0, AZ_EINVAL, "batch size must be a multiple of 16 in [16, %d], got %d", MAXB, max_batch);
     TDims d;
     memset(&d, 0, sizeof d);
@@ -1518,6 +1767,16 @@ static int enqueue_step_r(az_trainer *t) {
 }
 
 static int enqueue_step(az_trainer *t) {  // (row tiles, waves that split K, prefetch depth) by batch size: see "dense layers: shared pieces"
+    if (t->game == AZ_TICTACTOE) {
+        const int lds = ttt_lds_bytes(t->d.B);
+        if (!t->attrs_set) {
+            AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ttt_step), hipFuncAttributeMaxDynamicSharedMemorySize, ttt_lds_bytes(256)));
+            t->attrs_set = true;
+        }
+        hipLaunchKernelGGL(k_ttt_step, dim3(1), dim3(TPB), lds, t->stream, t->tq, t->d.B);
+        AZ_HIP(hipGetLastError());
+        return AZ_OK;
+    }
     const int RT = t->d.B / 16;
     if (RT <= 4) return enqueue_step_r<4, 16, 1>(t);
     if (RT <= 8) return enqueue_step_r<8, 8, 1>(t);
@@ -1530,7 +1789,8 @@ static int enqueue_step(az_trainer *t) {  // (row tiles, waves that split K, pre
 extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const float *d_pi, const int8_t *d_z, const int64_t *d_perm, int32_t n_steps,
                                 int32_t B, float *d_loss_pi, float *d_loss_v, void *stream) {
     AZ_REQUIRE(t && d_state && d_pi && d_z && d_perm && d_loss_pi && d_loss_v, AZ_EINVAL, "null argument");
-    AZ_REQUIRE(B >= 16 && B <= t->max_batch && B % 16 == 0, AZ_EINVAL, "batch size %d: need a multiple of 16 in [16, %d]", B, t->max_batch);
+    if (t->game == AZ_TICTACTOE) AZ_REQUIRE(B >= 2 && B <= t->max_batch, AZ_EINVAL, "batch size %d outside [2, %d]", B, t->max_batch);
+    else AZ_REQUIRE(B >= 16 && B <= t->max_batch && B % 16 == 0, AZ_EINVAL, "batch size %d: need a multiple of 16 in [16, %d]", B, t->max_batch);
     AZ_REQUIRE(n_steps >= 0, AZ_EINVAL, "negative step count");
     if (n_steps == 0) return AZ_OK;
     hipStream_t user = (hipStream_t)stream;
@@ -1546,6 +1806,7 @@ extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const floa
         t->d.B = B; t->d.S = S; t->d.NB = B * S < 256 ? B * S : 256;
     }
     t->q.state = d_state; t->q.pi = d_pi; t->q.z = d_z; t->q.perm = (const long long *)d_perm; t->q.loss_pi = d_loss_pi; t->q.loss_v = d_loss_v;
+    t->tq.state = d_state; t->tq.pi = d_pi; t->tq.z = d_z; t->tq.perm = (const long long *)d_perm; t->tq.loss_pi = d_loss_pi; t->tq.loss_v = d_loss_v;
     t->g_state = d_state; t->g_pi = d_pi; t->g_z = d_z; t->g_perm = d_perm; t->g_lp = d_loss_pi; t->g_lv = d_loss_v; t->g_B = B;
     const int zero2[2] = {0, 0};  // perm_off, loss_off: this call's arrays start at 0 (the step counter keeps running: dropout streams)
     AZ_HIP(hipMemcpyAsync(&t->q.hp->perm_off, zero2, sizeof zero2, hipMemcpyHostToDevice, t->stream));

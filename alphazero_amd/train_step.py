@@ -17,10 +17,15 @@ def _stream():
 
 
 def supports(module, batch_size):
-    """the hand-written step covers the conv nets at batch sizes that are multiples of 16 up to 512 (the reference's defaults: 64)"""
-    if not hasattr(module, "hip_shape") or not hasattr(module, "conv1"):
+    """the hand-written step covers the conv nets at batch sizes that are multiples of 16 up to 512 and the TicTacToe MLP at any batch
+    size from 2 to 256 (the reference's defaults: 64)"""
+    if not hasattr(module, "hip_shape"):
         return False
     gid, H, W = module.hip_shape()
+    if gid == 2:
+        return 2 <= batch_size <= 256
+    if not hasattr(module, "conv1"):
+        return False
     if gid == 0 and H not in (6, 8):
         return False
     if gid == 1 and not (5 <= H <= 8 and 5 <= W <= 8):

@@ -233,7 +233,7 @@ class AlphaZeroTrainer:
             self._hip_step = (key, HipTrainStep(self.nn_twin, max_batch=bs))
         ts = self._hip_step[1]
         ts.load(self.nn_twin)
-        ts.begin(c.learning_rate, 0.9, 0.0001, float(self.nn_twin.dropout), seed=(self.seed * 7919 + iter_idx * 104729 + 1) & 0xFFFFFFFF)
+        ts.begin(c.learning_rate, 0.9, 0.0001, float(getattr(self.nn_twin, "dropout", 0.0)), seed=(self.seed * 7919 + iter_idx * 104729 + 1) & 0xFFFFFFFF)
         self.loss_values[iter_idx] = {}
         lr = c.learning_rate
         state, pi, z = m["state"].contiguous(), m["pi"].contiguous(), m["z"].contiguous()

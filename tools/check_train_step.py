@@ -18,7 +18,8 @@ def make_net(tag, seed=0):
     from alphazero_amd.games.connect4 import Connect4Net
     from alphazero_amd.games.othello import OthelloNet
     torch.manual_seed(seed)
-    net = {"othello8": lambda: OthelloNet(n=8), "othello6": lambda: OthelloNet(n=6), "connect4": lambda: Connect4Net(7, 6)}[tag]()
+    from alphazero_amd.games.tictactoe import TicTacToeNet
+    net = {"othello8": lambda: OthelloNet(n=8), "othello6": lambda: OthelloNet(n=6), "connect4": lambda: Connect4Net(7, 6), "tictactoe": lambda: TicTacToeNet()}[tag]()
     with torch.no_grad():  # BatchNorm affine / running statistics away from their defaults, so that a mix-up shows
         for m in net.modules():
             if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
@@ -39,6 +40,12 @@ def make_samples(net, S, seed=1):
 def torch_step(net, x, pi, z, bs, masks=None, p=0.0):
     """forward + backward of the reference's loss with every intermediate kept (float64 module)"""
     keep = {}
+    if not hasattr(net, "conv1"):  # TicTacToeNet: the module's own forward (no workspace to compare: the step is one launch)
+        logp, v = net(x)
+        loss_pi = -torch.sum(pi * logp) / bs
+        loss_v = torch.sum((v - z) ** 2) / bs
+        (loss_pi + loss_v).backward()
+        return float(loss_pi.detach()), float(loss_v.detach()), keep
 
     def k(name, t):
         t.retain_grad()
@@ -122,7 +129,7 @@ def report(tag="othello8", B=64, steps=3, dropout=0.0, verbose=True, seed=0):
             masks = ((hip.debug("h1", (hip.max_batch, F1))[:B] != 0).double().cpu(), (hip.debug("h2", (hip.max_batch, F2))[:B] != 0).double().cpu())
         opt.zero_grad()
         t_pi, t_v, keep = torch_step(ref, x, pi[rws].double(), z[rws].double().unsqueeze(1), B, masks, dropout)
-        if s in (0, steps - 1):
+        if s in (0, steps - 1) and hasattr(net, "conv1"):
             pre = f"step{s}."
             for i in range(4):
                 c = keep[f"c{i + 1}"]
