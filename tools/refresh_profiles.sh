@@ -45,6 +45,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o k --
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_c2 -o k -- python3 $R/tools/run_config.py othello 4096 > $OUT/${TAG}_prof_c2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_c4 -o k -- python3 $R/tools/run_config.py connect4 8192 > $OUT/${TAG}_prof_c4.log 2>&1
 fi
+if [ $ONLY = all ] || [ $ONLY = train ] || [ $ONLY = bench ]; then
+# the hand-written training step: rocprofv3 stats of 500 steps at the reference's batch size and at 512
+cd /tmp
+for W in "othello8 64 500" "othello8 512 200" "connect4 64 500" "tictactoe 64 500"; do
+  set -- $W
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_train_$1_$2 -o k -- python3 $R/tools/train_step_bench.py $1 $2 $3 > $OUT/${TAG}_train_$1_$2.log 2>&1
+  f=$(find $OUT/${TAG}_prof_train_$1_$2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_train_$1_$2_kernel_stats.csv
+  rm -rf $OUT/${TAG}_prof_train_$1_$2
+done
+fi
 cd $R
 python3 tools/collect_profiles.py $TAG
 # gpurun copies back at most 64 MiB: keep the condensed files, drop the raw per-dispatch tables

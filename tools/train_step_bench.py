@@ -30,6 +30,6 @@ hip.steps(state, pi, z, perm, steps, B, lp, lv)
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-fl = {"othello8": 4339712, "othello6": 0, "connect4": 0}[tag]
+fl = {"othello8": 4339712}.get(tag, 0)
 print(f"{tag} batch {B}: {1e3 * dt / steps:.4f} ms per step ({steps} steps, host enqueue {1e3 * t_host / steps:.4f} ms per step)"
       + (f", {3 * fl * B * steps / dt / 1e12:.2f} TFLOP/s (3 x forward FLOPs)" if fl else "") + f"; last losses {lp[-1].item():.4f} {lv[-1].item():.4f}")
