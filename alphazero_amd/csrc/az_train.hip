@@ -278,13 +278,13 @@ __global__ __launch_bounds__(TPB) void k_conv1_fwd(TDims d, TPtr q) {
 // LDS: wl[288][LDP] weights (row tap*32+ic, column oc) | ain[(Hin+2 pad)(Win+2 pad)][LDP] input activation with a zero halo | pl[64][LDP]
 // | red[4 waves][16][LDP].  A board is shared by S workgroups (position tiles dealt round robin) and a tile's K by the four waves of
 // its workgroup: at 64 boards all 256 CUs work, and a layer with a single tile (conv4) no longer leaves three waves idle.
-#define CONV_FWD_LDS_FLOATS (288 * LDP + 100 * LDP + 64 * LDP + 64 * LDP + 4 * 32)
+#define CONV_FWD_LDS_FLOATS (288 * LDP + 100 * LDP + 64 * LDP + 64 * LDP + 4 * 32 + 64)
 #define CONV_FWD_LDS_BYTES (CONV_FWD_LDS_FLOATS * 4 + 8 * 32 * 3 * 8)
 __global__ __launch_bounds__(TPB) void k_conv_fwd(TDims d, TPtr q, int l /* 1..3 */) {
     extern __shared__ __align__(16) float lds[];
     float *wl = lds, *ain = wl + 288 * LDP, *pl = ain + 100 * LDP, *red = pl + 64 * LDP, *s_scale = red + 64 * LDP, *s_shift = s_scale + 32,
           *s_mean = s_shift + 32, *s_inv = s_mean + 32;
-    double *scr = (double *)(s_inv + 32);
+    double *scr = (double *)(s_inv + 32 + 64);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
     const int Hin = conv_hin(d, l), Win = conv_win(d, l), Hout = conv_hout(d, l), Wout = conv_wout(d, l), pad = l == 1 ? 1 : 0;
     const int Pin = Hin * Win, Pout = Hout * Wout, WP = Win + 2 * pad, MT = (Pout + 15) / 16;
@@ -316,6 +316,8 @@ __global__ __launch_bounds__(TPB) void k_conv_fwd(TDims d, TPtr q, int l /* 1..3
         *(float4 *)(wl + (e >> 5) * LDP + (e & 31)) = wreg[i];
     }
     for (int i = t; i < 100 * LDP; i += TPB) ain[i] = 0.0f;
+    int *pio = (int *)(s_inv + 32);  // input position -> offset of its cell in the haloed plane (no division in the board loop)
+    if (t < Pin) pio[t] = ((t / Win + pad) * WP + t % Win + pad) * LDP;
     TSTAMP(1, 1);
     __syncthreads();
     if (t < 32) fpart_finish(d, q, l - 1, scr, 3, 0, s_scale, s_shift, s_mean, s_inv);
@@ -328,20 +330,54 @@ __global__ __launch_bounds__(TPB) void k_conv_fwd(TDims d, TPtr q, int l /* 1..3
             const int i = t + TPB * k, p = i >> 5, ic = i & 31;
             if (i < Pin * 32) {
                 const float v = fmaf(r_c[k], s_scale[ic], s_shift[ic]);
-                ain[((p / Win + pad) * WP + p % Win + pad) * LDP + ic] = v > 0.0f ? v : 0.0f;
+                ain[pio[p] + ic] = v > 0.0f ? v : 0.0f;
             }
         }
         if (b + bstride < d.B) fetch(b + bstride);
         __syncthreads();
         TSTAMP(1, 3);
         int nloc = 0;  // rows of this workgroup's tiles that lie inside the plane (its tiles are mt = part, part + S, ...)
-        for (int mt = part; mt < MT; mt += S) {
+        const int my_tiles = (MT - part + S - 1) / S;
+        if (my_tiles >= 3) {
+            // three or four tiles: one tile per wave, its whole K in that wave (no reduction, no extra barrier)
+            const int mt = part + S * wave;
+            if (mt < MT) {
+                int m = 16 * mt + n16;
+                if (m >= Pout) m = Pout - 1;  // rows beyond the plane compute a copy of the last position; never stored
+                const int base = (m / Wout) * WP + m % Wout;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float *ap = ain + (base + (tap / 3) * WP + tap % 3) * LDP + kq;
+                    const float *wp = wl + (tap * 32 + kq) * LDP + n16;
+#pragma unroll
+                    for (int icb = 0; icb < 8; ++icb) {
+                        const float a = ap[icb * 4];
+                        acc0 = MFMA(a, wp[icb * 4 * LDP], acc0);
+                        acc1 = MFMA(a, wp[icb * 4 * LDP + 16], acc1);
+                    }
+                }
+                const float b0 = __shfl(bias_t, n16, 32), b1 = __shfl(bias_t, 16 + n16, 32);  // bias_t holds channel t & 31
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mm = 16 * mt + 4 * kq + r;
+                    if (mm < Pout) {
+                        const float v0 = acc0[r] + b0, v1 = acc1[r] + b1;
+                        cout[((size_t)b * Pout + mm) * 32 + n16] = v0; cout[((size_t)b * Pout + mm) * 32 + 16 + n16] = v1;
+                        pl[(16 * wave + 4 * kq + r) * LDP + n16] = v0; pl[(16 * wave + 4 * kq + r) * LDP + 16 + n16] = v1;
+                    }
+                }
+            }
+            for (int w = 0; w < my_tiles; ++w) nloc += min(16, Pout - 16 * (part + S * w));
+            __syncthreads();
+        } else
+        for (int mt = part; mt < MT; mt += S) {  // one or two tiles: a tile's 72 k-steps (9 taps x 8 blocks of 4 input channels) split over the four waves
             int m = 16 * mt + n16;
-            if (m >= Pout) m = Pout - 1;  // rows beyond the plane compute a copy of the last position; never stored
+            if (m >= Pout) m = Pout - 1;
             const int base = (m / Wout) * WP + m % Wout;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int jj = 0; jj < 18; ++jj) {  // the tile's 72 k-steps (9 taps x 8 blocks of 4 input channels) are split over the four waves
+            for (int jj = 0; jj < 18; ++jj) {
                 const int ks = 18 * wave + jj, tap = ks >> 3, icb = ks & 7, tr = (tap * 11) >> 5, tc = tap - 3 * tr;
                 const float a = ain[(base + tr * WP + tc) * LDP + icb * 4 + kq];
                 const float *wp = wl + (tap * 32 + icb * 4 + kq) * LDP + n16;
@@ -962,13 +998,13 @@ __global__ __launch_bounds__(NW * 64) void k_mix1(TDims d, TPtr q, int nw) {
 //   weight gradient dW[tap][ic][oc] += sum_p a_{l-1}[p + tap - pad][ic] dz[p][oc]                (M = ic, N = oc, K = positions), one
 //                   (ic tile, oc tile) pair per wave, nine accumulators that live across the workgroup's boards
 // LDS: wl[288][LDP] | dzp[<=100][LDP] dz with a zero halo of 2 - pad | ap[<=100][LDP] a_{l-1} with a zero halo of pad | xh[64][LDP] | dpl[64][LDP]
-#define CONV_BWD_LDS_FLOATS (288 * LDP + 100 * LDP + 100 * LDP + 64 * LDP + 64 * LDP + 10 * 32 + 128)
+#define CONV_BWD_LDS_FLOATS (288 * LDP + 100 * LDP + 100 * LDP + 64 * LDP + 64 * LDP + 10 * 32 + 192)
 #define CONV_BWD_LDS_BYTES (CONV_BWD_LDS_FLOATS * 4 + 2048 * 8)
 AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblocks, float *lds) {
     float *wl = lds, *dzp = wl + 288 * LDP, *ap = dzp + 100 * LDP, *xh = ap + 100 * LDP, *dpl = xh + 64 * LDP;
     float *k1 = dpl + 64 * LDP, *sh_o = k1 + 32, *mean_o = sh_o + 32, *inv_o = mean_o + 32, *k2 = inv_o + 32, *k3 = k2 + 32;
     float *sc_i = k3 + 32, *sh_i = sc_i + 32, *mean_i = sh_i + 32, *inv_i = mean_i + 32;
-    double *scr = (double *)(inv_i + 32 + 128);
+    double *scr = (double *)(inv_i + 32 + 192);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, ch = t & 31, grp = t >> 5;
     const int Hin = conv_hin(d, l), Win = conv_win(d, l), Hout = conv_hout(d, l), Wout = conv_wout(d, l), pad = l == 1 ? 1 : 0, hal = 2 - pad;
     const int Pin = Hin * Win, Pout = Hout * Wout, WZ = Wout + 2 * hal, WA = Win + 2 * pad, MTin = (Pin + 15) / 16;
@@ -1006,8 +1042,9 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
         *(float4 *)(wl + (e >> 5) * LDP + (e & 31)) = wreg[i];
     }
     for (int i = t; i < 200 * LDP; i += TPB) dzp[i] = 0.0f;  // dzp and ap (contiguous): the halos stay zero
-    int *pzo = (int *)(inv_i + 32), *pao = pzo + 64;  // output position -> offset of its cell in dzp / of its top-left tap in ap
+    int *pzo = (int *)(inv_i + 32), *pao = pzo + 64, *pio = pao + 64;  // output position -> offset of its cell in dzp / of its top-left tap in ap; input position -> its cell in ap
     if (t < Pout) { pzo[t] = ((t / Wout + hal) * WZ + t % Wout + hal) * LDP; pao[t] = ((t / Wout) * WA + t % Wout) * LDP; }
+    if (t < Pin) pio[t] = ((t / Win + pad) * WA + t % Win + pad) * LDP;
     __syncthreads();
     if (t < 32) {
         fpart_finish(d, q, l, scr, 8, 0, k1, sh_o, mean_o, inv_o);      // k1 = gamma_l / sqrt(var_l + eps)
@@ -1031,18 +1068,52 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
             const int i = t + TPB * k, p = i >> 5, cc = i & 31;
             if (i < Pout * 32) {
                 const float xo = (r_co[k] - mean_o[cc]) * inv_o[cc];
-                dzp[((p / Wout + hal) * WZ + p % Wout + hal) * LDP + cc] = k1[cc] * ((r_dy[k] - k2[cc]) - xo * k3[cc]);
+                dzp[pzo[p] + cc] = k1[cc] * ((r_dy[k] - k2[cc]) - xo * k3[cc]);
             }
             if (i < Pin * 32) {
                 const float a = fmaf(r_ci[k], sc_i[cc], sh_i[cc]);
-                ap[((p / Win + pad) * WA + p % Win + pad) * LDP + cc] = a > 0.0f ? a : 0.0f;
+                ap[pio[p] + cc] = a > 0.0f ? a : 0.0f;
                 xh[p * LDP + cc] = (r_ci[k] - mean_i[cc]) * inv_i[cc];
             }
         }
         if (b + bstride < d.B) fetch(b + bstride);
         __syncthreads();
         TSTAMP(3, 2);
-        for (int mt = part; mt < MTin; mt += S) {  // data gradient: this workgroup's position tiles, a tile's 72 k-steps split over the four waves
+        const int my_tiles = (MTin - part + S - 1) / S;
+        if (my_tiles >= 3) {  // data gradient, three or four tiles: one per wave with its whole K (no reduction)
+            const int mt = part + S * wave;
+            if (mt < MTin) {
+                int m = 16 * mt + n16;
+                if (m >= Pin) m = Pin - 1;
+                const int qr = m / Win, qc = m % Win;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float *zp = dzp + ((qr - tap / 3 + pad + hal) * WZ + qc - tap % 3 + pad + hal) * LDP + kq;
+                    const float *wp = wl + (tap * 32 + n16) * LDP + kq;
+#pragma unroll
+                    for (int ocb = 0; ocb < 8; ++ocb) {
+                        const float a = zp[4 * ocb];
+                        acc0 = MFMA(a, wp[4 * ocb], acc0);
+                        acc1 = MFMA(a, wp[16 * LDP + 4 * ocb], acc1);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mm = 16 * mt + 4 * kq + r;
+                    if (mm < Pin) {
+                        const float v0 = ap[pio[mm] + n16] > 0.0f ? acc0[r] : 0.0f, v1 = ap[pio[mm] + 16 + n16] > 0.0f ? acc1[r] : 0.0f;
+                        dyi[((size_t)b * Pin + mm) * 32 + n16] = v0; dyi[((size_t)b * Pin + mm) * 32 + 16 + n16] = v1;
+                        dpl[mm * LDP + n16] = v0; dpl[mm * LDP + 16 + n16] = v1;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int mm = grp; mm < Pin; mm += 8)  // this workgroup's rows: tiles part, part + S, ...
+                if (((mm >> 4) - part) % S == 0) { const double v = dpl[mm * LDP + ch]; s1 += v; s2 += v * (double)xh[mm * LDP + ch]; }
+            __syncthreads();
+        } else
+        for (int mt = part; mt < MTin; mt += S) {  // one or two tiles: a tile's 72 k-steps split over the four waves
             int m = 16 * mt + n16;
             if (m >= Pin) m = Pin - 1;
             const int qr = m / Win, qc = m % Win;
@@ -1063,7 +1134,7 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
                 const int rr = (t >> 5) + 8 * h, mm = 16 * mt + rr;
                 if (mm < Pin) {
                     const float g = (dpl[rr * LDP + ch] + dpl[(16 + rr) * LDP + ch]) + (dpl[(32 + rr) * LDP + ch] + dpl[(48 + rr) * LDP + ch]);
-                    const float v = ap[((mm / Win + pad) * WA + mm % Win + pad) * LDP + ch] > 0.0f ? g : 0.0f;
+                    const float v = ap[pio[mm] + ch] > 0.0f ? g : 0.0f;
                     dyi[((size_t)b * Pin + mm) * 32 + ch] = v;
                     s1 += v; s2 += (double)v * (double)xh[mm * LDP + ch];
                 }
@@ -1071,13 +1142,21 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
             __syncthreads();
         }
         TSTAMP(3, 3);
-#pragma unroll 4
-        for (int p0 = 0; p0 < Pout; p0 += 4) {  // weight gradient of this workgroup's taps ((tap & (S - 1)) == part): K = output positions, four per MFMA
-            const int p = p0 + kq, ok = p < Pout, oz = ok ? pzo[p] : 0, oa = ok ? pao[p] : 0;  // offsets of position p in dzp / ap (no division here)
-            const float bz = ok ? dzp[oz + 16 * wnt + n16] : 0.0f;
+        for (int p0 = 0; p0 < Pout; p0 += 8) {  // weight gradient of this workgroup's taps ((tap & (S - 1)) == part): K = output positions, four per MFMA,
+            // two k-steps per trip with every LDS operand read before the first MFMA (offsets from the tables: no division here)
+            const int pA = p0 + kq, pB = p0 + 4 + kq, okA = pA < Pout, okB = pB < Pout;
+            const int ozA = okA ? pzo[pA] : 0, oaA = okA ? pao[pA] : 0, ozB = okB ? pzo[pB] : 0, oaB = okB ? pao[pB] : 0;
+            const float bzA = okA ? dzp[ozA + 16 * wnt + n16] : 0.0f, bzB = okB ? dzp[ozB + 16 * wnt + n16] : 0.0f;
+            float aA[9], aB[9];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
-                if ((tap & (S - 1)) == part) wacc[tap] = MFMA(ap[oa + ((tap / 3) * WA + tap % 3) * LDP + 16 * wmt + n16], bz, wacc[tap]);
+                if ((tap & (S - 1)) == part) {
+                    aA[tap] = ap[oaA + ((tap / 3) * WA + tap % 3) * LDP + 16 * wmt + n16];
+                    aB[tap] = ap[oaB + ((tap / 3) * WA + tap % 3) * LDP + 16 * wmt + n16];
+                }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                if ((tap & (S - 1)) == part) { wacc[tap] = MFMA(aA[tap], bzA, wacc[tap]); wacc[tap] = MFMA(aB[tap], bzB, wacc[tap]); }
         }
         TSTAMP(3, 4);
         if (part == 0)
