@@ -147,9 +147,14 @@ class OthelloBoard(Board):
         return bool((legal >> (r * 8 + c)) & 1)
 
     def get_moves(self, player=None):
-        """legal cells in row-major order, or [pass_move] (the reference returns them in set order)"""
-        moves = [(b >> 3, b & 7) for b in R.bits(self._legal_bits(player))]
-        return moves if moves else [self.pass_move]
+        """legal cells, or [pass_move], in the reference's order: it collects them row-major into a set and returns list(set)
+        (othello.py:176-189), so a caller that seeds np.random sees the same get_random_move picks here as there"""
+        moves = set()
+        for b in R.bits(self._legal_bits(player)):
+            moves.add((b >> 3, b & 7))
+        if len(moves) == 0:
+            moves.add(self.pass_move)
+        return list(moves)
 
     def get_random_move(self, player=None):
         moves = self.get_moves(player)

@@ -45,6 +45,7 @@ def test_boards_side_by_side(R, tag):
             a, b = ref.get_moves(), mine.get_moves()
             key = (lambda m: int(m)) if tag.startswith("connect4") else (lambda m: (int(m[0]), int(m[1])))
             assert sorted(map(key, a)) == sorted(map(key, b))
+            assert list(map(key, a)) == list(map(key, b))  # the same ORDER too: a seeded np.random picks the same get_random_move on both
             other_a, other_b = ref.get_moves(player=-ref.player), mine.get_moves(player=-mine.player)
             assert sorted(map(key, other_a)) == sorted(map(key, other_b))
             mv = a[rng.randint(len(a))]
