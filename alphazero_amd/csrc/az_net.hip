@@ -1983,7 +1983,10 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
     n->FIN = game == AZ_TICTACTOE ? 9 : NCH * (n->CH - 4) * (n->CW - 4);
     n->NH = ((n->A + 1 + 15) / 16) * 16;
     if (game != AZ_TICTACTOE) {
-        bool ok = (n->CH == 8 && n->CW == 8) || (n->CH == 6 && n->CW == 6) || (n->CH == 7 && n->CW == 6);
+        // 8x8, 6x6 and 7x6 planes run the tuned kernels (k_trunk2 from 4096 boards up, Winograd conv2); every other plane between 5x5
+        // and 8x8 -- Connect4Net on the board sizes the engine plays (connect4.py:343-368) -- runs the one-board-per-wave kernel in the
+        // direct form at any batch size.  Planes below 5x5 leave conv4 without an output (the reference's forward fails there too).
+        bool ok = n->CH >= 5 && n->CH <= 8 && n->CW >= 5 && n->CW <= 8;
         if (!ok) { delete n; az_set_error("no conv-trunk kernel instantiated for a %dx%d plane", n->CH, n->CW); return AZ_EINVAL; }
         int rc = AZ_OK;
         float *p;
@@ -2652,13 +2655,38 @@ static int launch_tail(az_net *n, int B, float *probs, float *value, const int *
     return B >= r8 ? tail_go<192, 7, 8>(n, B, probs, value, dyn, st) : tail_go<192, 7, 4>(n, B, probs, value, dyn, st);
 }
 
+// the other planes between 5x5 and 8x8: k_trunk (one board per wave, direct form) at every batch size
+template <int CH, int CW>
+static int launch_trunk_plain(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
+    using G = TrunkGeom<CH, CW>;
+    static bool attr_set = false;
+    static int lds_bytes = G::LDS_BYTES;
+    if (!attr_set) {
+        if (160 * 1024 / 3 > G::LDS_BYTES) lds_bytes = (160 * 1024 / 3) & ~15;  // three blocks per CU, as launch_trunk
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk<CH, CW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    n->last_trunk_two_boards = 0;
+    hipLaunchKernelGGL((k_trunk<CH, CW, false>), dim3((B + 3) / 4), dim3(256), lds_bytes, st, in, B, dyn, n->tp, n->feat);
+    return AZ_OK;
+}
+
+static int launch_trunk_other(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
+#define PLANE(ch, cw) if (n->CH == ch && n->CW == cw) return launch_trunk_plain<ch, cw>(n, in, B, dyn, st);
+    PLANE(5, 5) PLANE(5, 6) PLANE(5, 7) PLANE(5, 8) PLANE(6, 5) PLANE(6, 7) PLANE(6, 8) PLANE(7, 5) PLANE(7, 7) PLANE(7, 8) PLANE(8, 5) PLANE(8, 6) PLANE(8, 7)
+#undef PLANE
+    az_set_error("no conv-trunk kernel instantiated for a %dx%d plane", n->CH, n->CW);
+    return AZ_EINVAL;
+}
+
 static int run_stage(az_net *n, int stage, const float *d_input, int B, const int *dyn, float *d_probs, float *d_value, hipStream_t st) {
     if (stage >= 1 && tail_is_fused(n)) return stage == 1 ? launch_tail(n, B, d_probs, d_value, dyn, st) : AZ_OK;  // stages 2, 3 ran inside stage 1
     switch (stage) {
         case 0:
             if (n->CH == 8 && n->CW == 8) return use_wino(8, 8) ? launch_trunk<8, 8, true>(n, d_input, B, dyn, st) : launch_trunk<8, 8, false>(n, d_input, B, dyn, st);
             if (n->CH == 6 && n->CW == 6) return launch_trunk<6, 6, false>(n, d_input, B, dyn, st);
-            return use_wino(7, 6) ? launch_trunk<7, 6, true>(n, d_input, B, dyn, st) : launch_trunk<7, 6, false>(n, d_input, B, dyn, st);
+            if (n->CH == 7 && n->CW == 6) return use_wino(7, 6) ? launch_trunk<7, 6, true>(n, d_input, B, dyn, st) : launch_trunk<7, 6, false>(n, d_input, B, dyn, st);
+            return launch_trunk_other(n, d_input, B, dyn, st);
         case 1: return launch_gemm(n->feat, n->fc1w, n->fc1b, n->h1, B, n->F1, n->FIN, true, dyn, st);
         case 2: return launch_gemm(n->h1, n->fc2w, n->fc2b, n->h2, B, n->F2, n->F1, true, dyn, st);
         default: return launch_heads(n, B, d_probs, d_value, dyn, st);
@@ -2799,7 +2827,10 @@ extern "C" int az_net_stage_kernel(const az_net *n, int stage, int B, char *buf,
     const char *name = "";
     if (n->game == AZ_TICTACTOE) name = "k_mlp";
     else if (stage >= 1 && tail_is_fused(n)) name = "k_tail_small";
-    else if (stage == 0) name = (!trunk_v1() && B >= 4096) ? (use_wino(n->CH, n->CW) ? "k_trunk2<Winograd conv2>" : "k_trunk2") : "k_trunk";
+    else if (stage == 0) {
+        const bool tuned = (n->CH == 8 && n->CW == 8) || (n->CH == 6 && n->CW == 6) || (n->CH == 7 && n->CW == 6);
+        name = (tuned && !trunk_v1() && B >= 4096) ? (use_wino(n->CH, n->CW) ? "k_trunk2<Winograd conv2>" : "k_trunk2") : "k_trunk";
+    }
     else if (stage == 3) name = (B <= 128 && n->NH <= 128 && n->F2 % 32 == 0) ? "k_heads_small" : (n->F2 == 512 ? "k_heads2" : "k_heads");
     else {
         const int N = stage == 1 ? n->F1 : n->F2, K = stage == 1 ? n->FIN : n->F1;

@@ -272,9 +272,9 @@ def test_device_fold_equals_host_fold(tag):
 
 def test_plane_shapes_without_a_trunk_kernel_are_refused():
     """the reference builds OthelloNet for any even n and Connect4Net for any width x height >= 4x4 (othello.py:316-339,
-    connect4.py:343-368); the HIP trunk is instantiated for 8x8, 6x6 and 7x6 planes (Othello 8 / 6, Connect4 6x7 and 8x8): everything else is AZ_EINVAL at
-    az_net_create, never a silent mis-tiled launch"""
-    for gid, H, W in ((1, 5, 6), (1, 6, 8), (1, 8, 7), (0, 4, 4)):
+    connect4.py:343-368); the HIP trunk covers every plane between 5x5 and 8x8 (below 5x5 conv4 has no output and the reference's own
+    forward fails): everything else is AZ_EINVAL at az_net_create, never a silent mis-tiled launch"""
+    for gid, H, W in ((1, 4, 4), (1, 4, 7), (0, 4, 4)):
         h = C.c_void_p()
         rc = E.lib().az_net_create(gid, H, W, 64, C.byref(h))
         assert rc == E._lib.AZ_EINVAL and b"no conv-trunk kernel" in E.lib().az_last_error()
@@ -282,6 +282,34 @@ def test_plane_shapes_without_a_trunk_kernel_are_refused():
     assert E.lib().az_net_create(0, 5, 5, 64, C.byref(h)) == E._lib.AZ_EINVAL  # odd Othello size: the reference's ValueError
     assert E.lib().az_net_create(1, 6, 7, 64, C.byref(h)) == 0
     E.lib().az_net_destroy(h)
+
+
+@pytest.mark.parametrize("H,W", [(5, 5), (5, 6), (6, 5), (6, 8), (8, 7), (7, 7), (7, 8), (5, 8)])
+def test_connect4_net_and_selfplay_on_other_board_sizes(H, W):
+    """Connect4Net on the other board sizes the engine plays (height H x width W; the plane is W x H, connect4.py:399): the network is
+    bit-equal to the oracle on random positions at three batch sizes (one-board-per-wave trunk at any size, the generic dense
+    kernels instead of the fused 6x7 tail), and a production-mode self-play run equals the oracle's sample for sample"""
+    from alphazero_amd.games.connect4 import Connect4Net
+    torch.manual_seed(10 * H + W)
+    net = Connect4Net(W, H).eval()
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+    onet = O.ConvNet(O.CONNECT4, H, W, sd)
+    hnet = E.HipNet(1, H, W, sd, max_batch=5000)
+    grids, players, _ = O.random_positions(O.CONNECT4, H, W, 21 + H + W, 400, 5000)
+    canon = (grids * players[:, None]).astype(np.float32)
+    for B in (1, 77, min(len(players), 4500)):
+        p, v = hnet.forward(torch.as_tensor(canon[:B], device="cuda"))
+        op, ov = onet.forward(canon[:B])
+        assert np.array_equal(p.cpu().numpy(), op) and np.array_equal(v.cpu().numpy(), ov), (H, W, B)
+    eng = E.SelfPlayEngine(1, H, W, n_slots=12, n_sim=24, net=hnet, seed=4, sample_capacity=20 * (H * W + 1))
+    got = eng.run(20)
+    meta = got["meta"].cpu().numpy()
+    order = np.lexsort((meta[:, 1], meta[:, 0]))
+    ref = O.selfplay(O.CONNECT4, H, W, 20, 24, ("conv", onet), seed=4)
+    for k in ("state", "z", "visits", "pi"):
+        assert np.array_equal(got[k].cpu().numpy()[order], ref[k]), (H, W, k)
+    eng.close()
+    hnet.close()
 
 
 @pytest.mark.parametrize("mode,tags", [("1", "othello8 connect4"), ("0", "othello8 connect4")])

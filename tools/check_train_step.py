@@ -19,7 +19,8 @@ def make_net(tag, seed=0):
     from alphazero_amd.games.othello import OthelloNet
     torch.manual_seed(seed)
     from alphazero_amd.games.tictactoe import TicTacToeNet
-    net = {"othello8": lambda: OthelloNet(n=8), "othello6": lambda: OthelloNet(n=6), "connect4": lambda: Connect4Net(7, 6), "tictactoe": lambda: TicTacToeNet()}[tag]()
+    net = {"othello8": lambda: OthelloNet(n=8), "othello6": lambda: OthelloNet(n=6), "connect4": lambda: Connect4Net(7, 6), "connect4_8x5": lambda: Connect4Net(8, 5),
+           "connect4_5x8": lambda: Connect4Net(5, 8), "tictactoe": lambda: TicTacToeNet()}[tag]()
     with torch.no_grad():  # BatchNorm affine / running statistics away from their defaults, so that a mix-up shows
         for m in net.modules():
             if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
