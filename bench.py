@@ -533,6 +533,20 @@ def main():
     job = Job()
     if job.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={job.world}")
+    dry = os.environ.get("AZ_BENCH_DRYRUN")
+    if dry:
+        # launcher rehearsal without a GPU (tests/test_dist.py): the ranks only rendezvous over gloo, reduce one number and rank 0 prints
+        # a stub line; "fail:<rank>" makes that rank exit non-zero after the rendezvous (the parent must then stop the others)
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(job.rank + 1)])
+        dist.all_reduce(t)
+        if dry.startswith("fail:") and int(dry.split(":")[1]) == job.rank:
+            sys.exit(7)
+        dist.barrier()
+        if job.rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": job.world, "sum_of_ranks_plus_one": float(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
 
     cpu = None
     if job.world == 1 and not args.no_cpu_baseline:  # before HIP is initialised: the worker processes are forked from a GPU-free parent

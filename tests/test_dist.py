@@ -111,3 +111,30 @@ def test_trainer_setup_hands_rank0_weights_to_every_rank():
     torch.manual_seed(1000)
     want = NETWORKS_REGISTER["othello"](config=OthelloConfig(board_size=6)).state_dict()
     assert all(torch.equal(ret[0][k], want[k]) for k in want)
+
+
+def _run_bench(env_extra, n):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_launcher_spawns_ranks_and_relays_rank0():
+    """`python bench.py --gpus N` started plainly is its own launcher: N child ranks with the torch.distributed environment, rank 0's
+    line on stdout (rehearsed here without a GPU: AZ_BENCH_DRYRUN makes the ranks rendezvous over gloo and stop)"""
+    import json
+    p = _run_bench({"AZ_BENCH_DRYRUN": "1"}, 4)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["sum_of_ranks_plus_one"] == 10.0
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    p = _run_bench({"AZ_BENCH_DRYRUN": "fail:2"}, 3)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "rank 2 exited with 7" in p.stderr
