@@ -1,7 +1,7 @@
 """GPU, opt-in (AZ_SOAK=1; ~3 minutes: the oracle needs ~2.5 s per Othello game): whole self-play runs at the BASELINE
 simulation counts with the real network, HIP engine vs CPU oracle, every sample compared bit for bit.
-Last runs: round 1, and round 2 on the final build (Winograd conv2 on 8x8 planes, k_heads2, fused Connect4 tail): 48 Othello 8x8
-games at 100 sims/move and 96 Connect4 games at 200: equal.  A trimmed version (8 / 16 games) runs in the default set
+The last green run of every round is recorded under profiles/ (r03_soak.txt: 48 Othello 8x8 games at 100 sims/move and 96 Connect4
+games at 200: equal).  A trimmed version (8 / 16 games) runs in the default set
 (tests/test_gpu_paths.py::test_selfplay_at_baseline_simulation_counts_equals_oracle)."""
 import os
 
