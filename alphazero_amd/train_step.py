@@ -83,6 +83,12 @@ class HipTrainStep:
         assert z.is_cuda and z.dtype == torch.int8 and perm.is_cuda and perm.dtype == torch.int64 and perm.is_contiguous()
         assert perm.numel() >= n_steps * batch_size and loss_pi.numel() >= n_steps and loss_v.numel() >= n_steps
         assert loss_pi.dtype == torch.float32 and loss_v.dtype == torch.float32 and loss_pi.is_cuda and loss_v.is_cuda
+        S = state.shape[0]
+        if pi.shape[0] != S or z.shape[0] != S:
+            raise ValueError(f"sample arrays disagree on the number of rows: state {S}, pi {pi.shape[0]}, z {z.shape[0]}")
+        used = perm[: n_steps * batch_size]
+        if used.numel() and (int(used.min()) < 0 or int(used.max()) >= S):  # once per epoch: the kernels index the samples unchecked
+            raise ValueError(f"permutation entries outside [0, {S})")
         check(lib().az_trainer_steps(self.h, state.data_ptr(), pi.data_ptr(), z.data_ptr(), perm.data_ptr(), n_steps, batch_size,
                                      loss_pi.data_ptr(), loss_v.data_ptr(), _stream()))
         self.steps_done += n_steps

@@ -119,6 +119,12 @@ def test_backends_are_selectable_and_unsupported_shapes_use_the_stock_step():
     assert train_step.supports(TicTacToeNet(), 16) and not train_step.supports(TicTacToeNet(), 300)
     with pytest.raises(ValueError):
         train_step.HipTrainStep(tr.nn, max_batch=520)
+    ts = train_step.HipTrainStep(tr.nn, max_batch=32)
+    m = tr.device_memory
+    bad = torch.full((32,), m["z"].shape[0], dtype=torch.int64, device="cuda")  # one past the last row
+    with pytest.raises(ValueError):
+        ts.steps(m["state"], m["pi"], m["z"], bad, 1, 32, torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda"))
+    ts.close()
 
 
 def test_dropout_law_and_determinism():
