@@ -44,3 +44,26 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("CPU oracle", "").replace("the oracle", "").lower() or f.endswith((".hip", ".h")), f
                 assert "liboracle" not in src and "az_oracle" not in src, f
+
+
+def test_counter_files_are_used_only_for_the_tree_they_were_measured_on(tmp_path, monkeypatch):
+    """bench.py takes profiles/traffic.json, mfma_counters.json, kstep_counters.json into its line only when their `csrc_sha` equals the
+    hash of the sources the running library was built from (round-2 verdict: file reads replayed into the driver's line)"""
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from alphazero_amd import _lib
+    h = _lib.csrc_tree_hash()
+    assert len(h) == 16 and h == _lib.csrc_tree_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "traffic.json").write_text(json.dumps({"othello_32768": {"k_trunk": 1}, "csrc_sha": h}))
+    d, why = bench.stamped("traffic.json")
+    assert d and d["othello_32768"]["k_trunk"] == 1 and h in why
+    (prof / "traffic.json").write_text(json.dumps({"othello_32768": {"k_trunk": 1}, "csrc_sha": "0" * 16}))
+    d, why = bench.stamped("traffic.json")
+    assert d is None and "dropped" in why
+    assert bench.stamped("missing.json")[0] is None
