@@ -22,7 +22,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("tag,B,steps,dropout", [("tictactoe", 16, 3, 0.0), ("tictactoe", 64, 3, 0.0), ("tictactoe", 250, 2, 0.0), ("othello8", 64, 3, 0.0), ("othello8", 64, 2, 0.3), ("othello6", 32, 2, 0.0), ("connect4", 32, 3, 0.0),
                                                  ("connect4", 128, 2, 0.3), ("othello8", 256, 1, 0.0), ("othello8", 512, 1, 0.0), ("connect4", 512, 1, 0.0),
-                                                 ("othello8", 16, 2, 0.0), ("othello6", 48, 2, 0.3), ("connect4_8x5", 32, 2, 0.0), ("connect4_5x8", 64, 2, 0.3)])
+                                                 ("othello8", 16, 2, 0.0), ("othello6", 48, 2, 0.3), ("connect4_8x5", 32, 2, 0.0), ("connect4_5x8", 64, 2, 0.3),
+                                                 # batch sizes that leave the row-tile templates partly filled (48: 3 of 4 tiles, 80: 5 of 8, 144: 9 of 16) and 320
+                                                 # boards on 256 workgroups (one or two boards each: unequal counts in the statistics partials)
+                                                 ("othello8", 48, 2, 0.3), ("othello6", 80, 2, 0.0), ("connect4", 144, 2, 0.3), ("othello8", 320, 1, 0.3)])
 def test_training_step_equals_torch_autograd(tag, B, steps, dropout):
     import check_train_step as C
     for seed in (0, 1, 2):
