@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the MI355X box (gpurun): counter passes, bench line, rocprofv3 kernel stats of the same command.
-# usage: tools/refresh_profiles.sh TAG [all|net|kstep|bench]   -> gpurun_out/TAG_*  (tools/collect_profiles.py condenses; copy into profiles/)
+# usage: tools/refresh_profiles.sh TAG [all|net|kstep|bench|train]   -> gpurun_out/TAG_*  (tools/collect_profiles.py condenses; copy into profiles/)
 # Counter passes first (bench.py reads profiles/traffic.json, mfma_counters.json, kstep_counters.json).  Every pass is
 # its own rocprofv3 run with --kernel-trace only (no --stats, no other trace domain), the program directly after `--`.
 set -o pipefail
@@ -12,7 +12,7 @@ pass() {  # name, counters, program args...
   local name=$1 ctr=$2; shift 2
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${TAG}_$name -o k -- python3 "$@" > $OUT/${TAG}_$name.log 2>&1 || echo "pass $name failed (see $OUT/${TAG}_$name.log)"
 }
-ONLY=${2:-all}   # all | net | kstep | bench
+ONLY=${2:-all}   # all | net | kstep | bench | train
 if [ $ONLY = all ] || [ $ONLY = net ]; then
 for W in "othello 32768" "othello 4096" "connect4 8192"; do
   set -- $W; g=$1; b=$2
