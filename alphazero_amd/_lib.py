@@ -37,7 +37,7 @@ SYMBOLS = [
     "az_net_create", "az_net_destroy", "az_net_set_tensor", "az_net_commit", "az_net_set_tensor_device", "az_net_commit_device", "az_net_forward", "az_net_forward_dyn",
     "az_net_action_size",
     "az_net_flops_per_board", "az_net_time_stage", "az_net_stage_kernel", "az_net_profile", "az_net_profiling", "az_net_profile_read", "az_net_profile_overhead", "az_engine_create", "az_engine_destroy", "az_engine_run",
-    "az_engine_get_stats", "az_engine_samples", "az_engine_set_roots", "az_engine_search", "az_engine_advance",
+    "az_engine_get_stats", "az_engine_samples", "az_engine_set_roots", "az_engine_search", "az_engine_search_begin", "az_engine_search_end", "az_engine_pair", "az_engine_advance",
     "az_engine_root_children", "az_engine_nodes_used", "az_engine_grow_pools", "az_engine_play", "az_augment_count", "az_augment",
     "az_engine_set_sides", "az_engine_best_moves", "az_engine_baseline_moves", "az_engine_root_status",
     "az_trainer_create", "az_trainer_destroy", "az_trainer_load", "az_trainer_store", "az_trainer_begin", "az_trainer_set_lr",
@@ -84,6 +84,9 @@ def lib():
                                     C.POINTER(vp)]
     L.az_engine_set_roots.argtypes = [vp, vp, vp, vp, vp, i32]
     L.az_engine_search.argtypes = [vp, i32]
+    L.az_engine_search_begin.argtypes = [vp, i32]
+    L.az_engine_search_end.argtypes = [vp]
+    L.az_engine_pair.argtypes = [vp, vp]
     L.az_engine_advance.argtypes = [vp]
     L.az_engine_play.argtypes = [vp, vp, i32, vp]
     L.az_engine_set_sides.argtypes = [vp, vp, i32]

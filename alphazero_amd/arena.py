@@ -81,6 +81,7 @@ class BatchedArena:
                                                       board_width, board_height)
         self.nn, self.opponent, self.n_sim, self.seed = nn, opponent, n_sim, seed
         self.opponent_n_sim = opponent_n_sim if opponent_n_sim is not None else n_sim
+        self.overlap = True  # two tree players search at the same time (each on its own stream); False: one after the other
         self.tie_mode = None  # None: fair_max draws among equals (utils.py:28-34); tests pin it to engine.TIE_LOWEST (golden G7)
 
     def _engine(self, net, G, n_sim, seed):
@@ -151,17 +152,28 @@ class BatchedArena:
             e2 = self._engine(self.opponent, G, self.opponent_n_sim, self.seed + 1)
             e2.set_roots(grids, ones, game_ids=ids)
             e2.set_sides(-side1)
+            if self.overlap:
+                e1.pair_with(e2)
         for _ in range(4 * self.H * self.W + 8):
             _, over, winner, score = e1.root_status()
             if over.all():
                 break
-            e1.search(self.n_sim)
-            a = e1.best_moves()
-            if e2 is not None:
-                e2.search(self.opponent_n_sim)
-                b = e2.best_moves()
+            if e2 is not None and self.overlap:  # both players think at once: each engine searches the slots where its colour is to move, on its own stream
+                e1.search_begin(self.n_sim)
+                try:
+                    e2.search_begin(self.opponent_n_sim)
+                    e2.search_end()
+                finally:
+                    e1.search_end()
+                a, b = e1.best_moves(), e2.best_moves()
             else:
-                b = e1.baseline_moves(self.opponent, seed=self.seed + 7)
+                e1.search(self.n_sim)
+                a = e1.best_moves()
+                if e2 is not None:
+                    e2.search(self.opponent_n_sim)
+                    b = e2.best_moves()
+                else:
+                    b = e1.baseline_moves(self.opponent, seed=self.seed + 7)
             moves = np.where(a >= 0, a, b).astype(np.int32)
             if record_moves:
                 self.moves.append(moves.copy())
@@ -170,6 +182,7 @@ class BatchedArena:
                 e2.play(moves)
         else:
             raise RuntimeError("arena games did not finish")
+        self.engine_stats = [e.stats() for e in (e1, e2) if e is not None]  # graph replays, lock-steps, evaluated rows
         e1.close()
         if e2 is not None:
             e2.close()

@@ -1049,6 +1049,7 @@ struct az_engine {
     // The engine runs on a stream of its own (graph capture is not allowed on the legacy default stream); every entry
     // point first orders it behind the caller's stream and returns only after its own stream has drained.
     hipStream_t user_stream = nullptr;
+    bool search_open = false;  // between az_engine_search_begin and _end
     hipEvent_t ev_in = nullptr;
     // One search = 1 + 5 n_sim kernel launches: captured once per (n_sim, batch cap) as a HIP graph and replayed
     std::map<unsigned long long, hipGraphExec_t> graphs;
@@ -1358,6 +1359,46 @@ extern "C" int az_engine_search(az_engine *e, int32_t n_sim) {
     AZ_TRY(do_search(e, n_sim));
     AZ_TRY(fetch_counters(e));
     return check_err(e);
+}
+
+// az_engine_search in two halves: _begin queues the search on the engine's stream and returns, _end waits for it and reports its
+// errors.  Between the two the caller may start the search of ANOTHER engine (the arena's two players think at the same time on
+// disjoint slots: two latency-bound launch chains side by side); no other entry point of THIS engine may be called in between.
+extern "C" int az_engine_search_begin(az_engine *e, int32_t n_sim) {
+    AZ_REQUIRE(e && n_sim > 0, AZ_EINVAL, "bad arguments");
+    AZ_REQUIRE(!e->search_open, AZ_ESTATE, "az_engine_search_begin: the previous search has not been ended");
+    AZ_TRY(enter(e));
+    AZ_TRY(do_search(e, n_sim));
+    e->search_open = true;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_search_end(az_engine *e) {
+    AZ_REQUIRE(e, AZ_EINVAL, "null argument");
+    AZ_REQUIRE(e->search_open, AZ_ESTATE, "az_engine_search_end without az_engine_search_begin");
+    e->search_open = false;
+    AZ_TRY(fetch_counters(e));
+    return check_err(e);
+}
+
+// Two engines whose searches are to overlap (az_engine_search_begin on both) need streams on DIFFERENT hardware queues.  The HIP
+// runtime deals its few hardware queues (four by default) out to streams of one priority in turn, so two streams of a process that
+// has made others (torch's, a trainer's) may share a queue and then run strictly one after the other (measured: an arena inside
+// the trainer's process gained nothing from the overlap).  Queues of different priorities come from different pools: `b` gets a
+// new stream of the highest priority.  Call before b's first search.
+extern "C" int az_engine_pair(az_engine *a, az_engine *b) {
+    AZ_REQUIRE(a && b && a != b, AZ_EINVAL, "two different engines are needed");
+    AZ_REQUIRE(!a->search_open && !b->search_open, AZ_ESTATE, "az_engine_pair: a search is open");
+    AZ_REQUIRE(b->graphs.empty(), AZ_ESTATE, "az_engine_pair must come before the second engine's searches");
+    int least = 0, greatest = 0;  // numerically lower = higher priority
+    AZ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (least == greatest) return AZ_OK;  // no priorities on this device: nothing to do
+    hipStream_t s = nullptr;
+    AZ_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest));
+    AZ_HIP(hipStreamSynchronize(b->stream));
+    (void)hipStreamDestroy(b->stream);
+    b->stream = s;
+    return AZ_OK;
 }
 
 extern "C" int az_engine_advance(az_engine *e) {

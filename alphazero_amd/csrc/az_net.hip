@@ -1453,6 +1453,92 @@ __global__ __launch_bounds__(64) void k_dense_small(const float *__restrict__ X,
     if (n < N) Y[(size_t)m * N + n] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_dense_frag: fc1 / fc2 for everything below the row counts that fill the chip with k_gemm's tiles (a single game's search, arenas,
+// self-play waves of a few hundred to a few thousand games).  There the layer's time is the length of ONE accumulation chain, not
+// the chip's FLOPs: k_gemm walks K in 32x32x2 steps (k += 2 per 64 cycles: 15 us for K = 1024 whatever the row count, 20 / 37.5 us
+// measured for fc1 / fc2 from 256 to 2048 rows), k_dense_small in dependent fmas (19 us).  v_mfma_f32_16x16x4_f32 advances k by 4
+// every 32 cycles -- a chain four times shorter for the same K -- and a 16x16 tile per wave gives 2048 waves already at 512 rows.
+// The scheme is k_heads2's: workgroup = NT waves, wave t owns column tile blockIdx.x * NT + t of the block's 16 rows; the rows go to
+// LDS once; the weights never touch LDS: a copy in B-fragment order [K/16][N/16][64 lanes][4 k-steps] (k_retile_q, made at commit
+// time from the folded [K][N] matrix: a permutation, same values) is streamed from L2 with one coalesced 16-byte load per 16 k,
+// PF loads ahead.  Accumulation: bias, then k ascending -- the chain of k_gemm / k_dense_small / the oracle: identical bits.
+// ---------------------------------------------------------------------------------------------
+template <bool RELU, int NT>
+__global__ __launch_bounds__(64 * NT) void k_dense_frag(const float *__restrict__ X, const float *__restrict__ Wq, const float *__restrict__ bias,
+                                                        float *__restrict__ Y, int M, int N, int K, const int *__restrict__ dyn_count) {
+    if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
+    constexpr int NTHR = 64 * NT, PF = 8;
+    const int brow0 = blockIdx.y * 16;
+    if (brow0 >= M) return;  // uniform
+    extern __shared__ __attribute__((aligned(16))) float dfs[];  // [16][K + 4]: row stride = 4 mod 64 banks, the fragment reads are conflict-free
+    const int XSTR = K + 4, NKB = K / 16, NTILES = N / 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kq = lane >> 4;
+    const int ct = blockIdx.x * NT + wave;
+    const float4 *wq = reinterpret_cast<const float4 *>(Wq) + (size_t)ct * 64 + lane;
+    const size_t wstep = (size_t)NTILES * 64;
+    float4 bq[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) bq[p] = wq[(size_t)p * wstep];  // in flight while the rows are staged
+    const float bv = bias[ct * 16 + m];
+    {   // the block's 16 rows -> LDS (rows past M repeat the last row: finite operands, never stored); K % 64 == 0
+        const int kv = K / 4, nv = 16 * kv;
+        for (int q0 = 0; q0 < nv; q0 += 4 * NTHR) {
+            float4 rx[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = q0 + tid + NTHR * i;
+                rx[i] = make_float4(0, 0, 0, 0);
+                if (q < nv) {
+                    int row = brow0 + q / kv;
+                    row = row < M ? row : M - 1;
+                    rx[i] = reinterpret_cast<const float4 *>(X + (size_t)row * K)[q % kv];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = q0 + tid + NTHR * i;
+                if (q < nv) *reinterpret_cast<float4 *>(dfs + (q / kv) * XSTR + 4 * (q % kv)) = rx[i];
+            }
+        }
+    }
+    __syncthreads();
+    f32x4 acc = (f32x4){bv, bv, bv, bv};
+    const float *xa = dfs + m * XSTR + kq;  // A fragment of k-step ks: xa[4 * ks]
+    for (int kb0 = 0; kb0 < NKB; kb0 += PF) {  // NKB % PF == 0
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int kb = kb0 + p;
+            const float4 b = bq[p];
+            if (kb + PF < NKB) bq[p] = wq[(size_t)(kb + PF) * wstep];
+            const float a0 = xa[16 * kb], a1 = xa[16 * kb + 4], a2 = xa[16 * kb + 8], a3 = xa[16 * kb + 12];
+            __builtin_amdgcn_sched_barrier(0);  // loads stay issued ahead of this block's MFMAs
+            acc = MFMA(a0, b.x, acc);
+            acc = MFMA(a1, b.y, acc);
+            acc = MFMA(a2, b.z, acc);
+            acc = MFMA(a3, b.w, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // C layout of 16x16x4: column lane & 15, rows 4 (lane >> 4) + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = brow0 + 4 * kq + r;
+        float v = acc[r];
+        if (RELU) v = v > 0.0f ? v : 0.0f;
+        if (row < M) Y[(size_t)row * N + ct * 16 + m] = v;
+    }
+}
+
+// dst[kb][nt][lane][i] = W[k = 16 kb + 4 i + (lane >> 4)][n = 16 nt + (lane & 15)] of a folded [K][N] matrix (k_dense_frag's weights)
+__global__ void k_retile_q(const float *__restrict__ W, float *__restrict__ dst, int K, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * N) return;
+    const int ii = i % 4, lane = (i / 4) % 64, NTL = N / 16, nt = (i / 256) % NTL, kb = i / (256 * NTL);
+    dst[i] = W[(size_t)(16 * kb + 4 * ii + (lane >> 4)) * N + 16 * nt + (lane & 15)];
+}
+
 template <int BM, int BN>
 constexpr int gemm_lds_bytes() { return 4 * (2 * BM * (32 + 1) + 2 * 32 * BN); }
 
@@ -1937,6 +2023,9 @@ __global__ void k_mlp(const float *__restrict__ in, int B, const int *__restrict
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// layers k_dense_frag can run: K in whole 128-k groups of fragments (PF = 8 loads of 16 k), the 16 rows of K + 4 floats within the LDS
+static bool frag_shape(int N, int K) { return N % 64 == 0 && K % 128 == 0 && K <= 2048; }
+
 struct az_net {
     int game, H, W, CH, CW, A, F1, F2, FIN, NH, max_batch;
     std::map<std::string, std::vector<float>> raw;
@@ -1945,6 +2034,7 @@ struct az_net {
     TrunkParams tp;
     float *fc1w, *fc1b, *fc2w, *fc2b, *hw, *hb;
     float *hwq = nullptr;  // head matrix in 16x16x4 B-fragment order [F2/16][NH/16][64 lanes][4] (k_heads2)
+    float *fc1wq = nullptr, *fc2wq = nullptr;  // fc1 / fc2 in the same fragment order (k_dense_frag); null where the shapes do not tile
     float *feat, *h1, *h2;
     MlpParams mlp;           // host staging of the TicTacToe MLP
     MlpParams *mlp_dev = nullptr;  // what k_mlp reads
@@ -1998,6 +2088,8 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
         NA(n->tp.wu, 2 * 8 * 4 * 64 * 4) NA(n->tp.wu32, 4 * 16 * 64 * 4)
         NA(n->fc1w, (size_t)n->FIN * n->F1) NA(n->fc1b, n->F1) NA(n->fc2w, (size_t)n->F1 * n->F2) NA(n->fc2b, n->F2)
         NA(n->hw, (size_t)n->F2 * n->NH) NA(n->hb, n->NH) NA(n->hwq, (size_t)n->F2 * n->NH)
+        if (frag_shape(n->F1, n->FIN)) { NA(n->fc1wq, (size_t)n->FIN * n->F1) }
+        if (frag_shape(n->F2, n->F1)) { NA(n->fc2wq, (size_t)n->F1 * n->F2) }
         NA(n->feat, (size_t)max_batch * n->FIN) NA(n->h1, (size_t)max_batch * n->F1) NA(n->h2, (size_t)max_batch * n->F2)
 #undef NA
         if (rc != AZ_OK) { az_net_destroy(n); return rc; }
@@ -2064,6 +2156,14 @@ static int bn_scale(az_net *n, const std::string &bn, int C, std::vector<double>
 static int upload(float *dst, const std::vector<float> &src, hipStream_t st) {
     AZ_HIP(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice, st));
     AZ_HIP(hipStreamSynchronize(st));  // src is a temporary
+    return AZ_OK;
+}
+
+// the folded [K][N] matrix once more in B-fragment order (k_dense_frag); a layer whose shape does not tile has no such copy
+static int retile_q(const float *w, float *dst, int K, int N, hipStream_t st) {
+    if (!dst) return AZ_OK;
+    hipLaunchKernelGGL(k_retile_q, dim3((unsigned)(((size_t)K * N + 255) / 256)), dim3(256), 0, st, w, dst, K, N);
+    AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
 
@@ -2191,6 +2291,7 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
             for (int k = 0; k < n->FIN; ++k) fw[(size_t)k * n->F1 + j] = (float)((double)(*w)[(size_t)j * n->FIN + k] * s[j]);
         }
         AZ_TRY(upload(n->fc1w, fw, st)); AZ_TRY(upload(n->fc1b, fb, st));
+        AZ_TRY(retile_q(n->fc1w, n->fc1wq, n->FIN, n->F1, st));
     }
     {
         AZ_TRY(bn_scale(n, "fc_bn2", n->F2, s, mean, beta));
@@ -2201,6 +2302,7 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
             for (int k = 0; k < n->F1; ++k) fw[(size_t)k * n->F2 + j] = (float)((double)(*w)[(size_t)j * n->F1 + k] * s[j]);
         }
         AZ_TRY(upload(n->fc2w, fw, st)); AZ_TRY(upload(n->fc2b, fb, st));
+        AZ_TRY(retile_q(n->fc2w, n->fc2wq, n->F1, n->F2, st));
     }
     {
         const std::vector<float> *pw, *pb, *vw, *vb;
@@ -2392,8 +2494,10 @@ extern "C" int az_net_commit_device(az_net *n, void *stream) {
     }
     AZ_TRY(fold_launch(n, FOLD_DENSE_T, n->fc1w, n->FIN * n->F1, "fc1.weight", (size_t)n->F1 * n->FIN, "", 0, "fc_bn1", n->F1, n->FIN, n->F1, 0, st));
     AZ_TRY(fold_launch(n, FOLD_BIAS, n->fc1b, n->F1, "", 0, "fc1.bias", n->F1, "fc_bn1", n->F1, 0, 0, 0, st));
+    AZ_TRY(retile_q(n->fc1w, n->fc1wq, n->FIN, n->F1, st));
     AZ_TRY(fold_launch(n, FOLD_DENSE_T, n->fc2w, n->F1 * n->F2, "fc2.weight", (size_t)n->F2 * n->F1, "", 0, "fc_bn2", n->F2, n->F1, n->F2, 0, st));
     AZ_TRY(fold_launch(n, FOLD_BIAS, n->fc2b, n->F2, "", 0, "fc2.bias", n->F2, "fc_bn2", n->F2, 0, 0, 0, st));
+    AZ_TRY(retile_q(n->fc2w, n->fc2wq, n->F1, n->F2, st));
     AZ_TRY(fold_launch(n, FOLD_HEADS_W, n->hw, n->F2 * n->NH, "fc_probs.weight", (size_t)n->A * n->F2, "fc_value.weight", n->F2, "", 0, n->F2, n->NH, n->A, st));
     AZ_TRY(fold_launch(n, FOLD_HEADS_B, n->hb, n->NH, "fc_probs.bias", n->A, "fc_value.bias", 1, "", 0, 0, n->NH, n->A, st));
     if (n->F2 % 16 == 0)
@@ -2514,9 +2618,20 @@ static int solo_t_launch(const float *A, const float *Bw, const float *bias, flo
 }
 
 // which kernel a dense layer of M rows runs on (one place: launch_gemm dispatches on it, az_net_stage_kernel reports it)
-enum GemmKind { GK_SMALL, GK_SOLO, GK_SOLO_T, GK_TILED };
+enum GemmKind { GK_SMALL, GK_FRAG, GK_SOLO, GK_SOLO_T, GK_TILED };
 static int gemm_solo_env() { static int solo = -2; if (solo == -2) { const char *e = getenv("AZ_GEMM_SOLO"); solo = e ? atoi(e) : -1; } return solo; }
-static GemmKind gemm_kind(int M, int N, int K) {
+// rows up to which k_dense_frag runs a layer.  Measured on OthelloNet 8x8 (us, k_dense_frag | what ran before: k_dense_small up to 128 / 256
+// rows, k_gemm above): fc1 (K = 512) 6.6 | 8.7 at 1 row, 7.3 | 21.0 at 256, 9.9 | 20.9 at 512, 16.3 | 21.2 at 1024, 22.3 | 21.0 at 1536;
+// fc2 (K = 1024) 11.2 | 15.9 at 1 row, 11.7 | 24.1 at 256, 11.9 | 39.8 at 512, 17.5 | 39.8 at 1024, 28.2 | 40.0 at 1536, 34.5 | 40.0 at 2048,
+// 65 | 37 at 4096 (every 16 rows stream the whole weight matrix from L2: ~9 TB/s from 1024 rows up, the kernel's bound there).
+// AZ_DENSE_FRAG_MAX overrides both limits; 0 switches the kernel off (the kernels of the rounds before).
+static int frag_max_rows(int K) {
+    static int v = -2;
+    if (v == -2) { const char *e = getenv("AZ_DENSE_FRAG_MAX"); v = e ? atoi(e) : -1; }
+    return v >= 0 ? v : (K >= 1024 ? 2048 : 1024);
+}
+static GemmKind gemm_kind(int M, int N, int K, bool have_q = true) {
+    if (have_q && M <= frag_max_rows(K) && frag_shape(N, K)) return GK_FRAG;  // latency-bound row counts: the shortest accumulation chain
     // measured crossover against the tiled GEMM (MI355X): K = 512 up to 128 rows (15 vs 21 us), K = 1024 up to 256 rows (28 vs 40 us)
     if (M <= (K >= 1024 ? 256 : 128) && K % 32 == 0) return GK_SMALL;  // few rows: latency matters, not throughput
     // large row counts: the one-wave-per-SIMD kernel (256x256 workgroup tiles), from one tile per CU up.  AZ_GEMM_SOLO=0 / 1 forces.
@@ -2534,9 +2649,25 @@ static GemmKind gemm_kind(int M, int N, int K) {
     return GK_TILED;
 }
 
-static int launch_gemm(const float *A, const float *Bw, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
+static int frag_go(const float *A, const float *Bq, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
+    constexpr int NT = 4;
+    const int lds = 4 * 16 * (K + 4);
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_frag<true, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense_frag<false, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_lds = lds;
+    }
+    dim3 grid((unsigned)(N / (16 * NT)), (unsigned)((M + 15) / 16));
+    if (relu) hipLaunchKernelGGL((k_dense_frag<true, NT>), grid, dim3(64 * NT), lds, st, A, Bq, bias, C, M, N, K, dyn);
+    else hipLaunchKernelGGL((k_dense_frag<false, NT>), grid, dim3(64 * NT), lds, st, A, Bq, bias, C, M, N, K, dyn);
+    return AZ_OK;
+}
+
+static int launch_gemm(const float *A, const float *Bw, const float *Bq, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
     AZ_REQUIRE(K % 32 == 0, AZ_EINVAL, "GEMM K=%d is not a multiple of 32", K);
-    switch (gemm_kind(M, N, K)) {
+    switch (gemm_kind(M, N, K, Bq != nullptr)) {
+        case GK_FRAG: return frag_go(A, Bq, bias, C, M, N, K, relu, dyn, st);
         case GK_SMALL: {
             dim3 grid((unsigned)((N + 63) / 64), (unsigned)M);
             if (relu) hipLaunchKernelGGL((k_dense_small<true>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
@@ -2687,8 +2818,8 @@ static int run_stage(az_net *n, int stage, const float *d_input, int B, const in
             if (n->CH == 6 && n->CW == 6) return launch_trunk<6, 6, false>(n, d_input, B, dyn, st);
             if (n->CH == 7 && n->CW == 6) return use_wino(7, 6) ? launch_trunk<7, 6, true>(n, d_input, B, dyn, st) : launch_trunk<7, 6, false>(n, d_input, B, dyn, st);
             return launch_trunk_other(n, d_input, B, dyn, st);
-        case 1: return launch_gemm(n->feat, n->fc1w, n->fc1b, n->h1, B, n->F1, n->FIN, true, dyn, st);
-        case 2: return launch_gemm(n->h1, n->fc2w, n->fc2b, n->h2, B, n->F2, n->F1, true, dyn, st);
+        case 1: return launch_gemm(n->feat, n->fc1w, n->fc1wq, n->fc1b, n->h1, B, n->F1, n->FIN, true, dyn, st);
+        case 2: return launch_gemm(n->h1, n->fc2w, n->fc2wq, n->fc2b, n->h2, B, n->F2, n->F1, true, dyn, st);
         default: return launch_heads(n, B, d_probs, d_value, dyn, st);
     }
 }
@@ -2834,8 +2965,9 @@ extern "C" int az_net_stage_kernel(const az_net *n, int stage, int B, char *buf,
     else if (stage == 3) name = (B <= 128 && n->NH <= 128 && n->F2 % 32 == 0) ? "k_heads_small" : (n->F2 == 512 ? "k_heads2" : "k_heads");
     else {
         const int N = stage == 1 ? n->F1 : n->F2, K = stage == 1 ? n->FIN : n->F1;
-        switch (gemm_kind(B, N, K)) {
+        switch (gemm_kind(B, N, K, (stage == 1 ? n->fc1wq : n->fc2wq) != nullptr)) {
             case GK_SMALL: name = "k_dense_small"; break;
+            case GK_FRAG: name = "k_dense_frag"; break;
             case GK_SOLO: name = "k_gemm_solo"; break;
             case GK_SOLO_T: name = "k_gemm_solo_t"; break;
             default: name = "k_gemm"; break;

@@ -257,6 +257,17 @@ class SelfPlayEngine:
     def search(self, n_sim):
         check(lib().az_engine_search(self.h, n_sim))
 
+    def search_begin(self, n_sim):
+        """queues the search and returns; search_end() waits for it (another engine may search in between: the arena's two players)"""
+        check(lib().az_engine_search_begin(self.h, n_sim))
+
+    def pair_with(self, other):
+        """puts `other`'s stream on a hardware queue of its own so that overlapped searches of the two engines run side by side"""
+        check(lib().az_engine_pair(self.h, other.h))
+
+    def search_end(self):
+        check(lib().az_engine_search_end(self.h))
+
     def advance(self):
         check(lib().az_engine_advance(self.h))
 

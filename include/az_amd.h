@@ -183,6 +183,14 @@ int az_engine_grow_pools(az_engine *e, int32_t node_capacity);
 int az_engine_set_sides(az_engine *e, const int8_t *h_sides, int32_t n);
 int az_engine_best_moves(az_engine *e, int32_t *h_actions);
 int az_engine_baseline_moves(az_engine *e, int32_t kind, uint32_t seed, int32_t *h_actions);
+/* az_engine_search in two halves, so that the arena's two players (arena.py:135-140: player1.get_move / player2.get_move, each on
+ * the games where it is to move) think at the same time: _begin queues the search on the engine's own stream and returns, _end
+ * waits for it and reports what az_engine_search would have.  Only calls on OTHER engines may come between the two. */
+int az_engine_search_begin(az_engine *e, int32_t n_sim);
+/* puts b's stream on a hardware queue that a's does not share (a stream of another priority), so that the two searches really
+ * run side by side; before b's first search */
+int az_engine_pair(az_engine *a, az_engine *b);
+int az_engine_search_end(az_engine *e);
 int az_engine_root_status(az_engine *e, int8_t *h_players, uint8_t *h_over, int8_t *h_winner, int32_t *h_score);
 
 /* ---- symmetry augmentation on the device ------------------------------------

@@ -158,3 +158,42 @@ def test_batched_arena_equals_oracle_arena_on_othello8():
         moves, winners, scores, ostats = oracle_arena((O.OTHELLO, 8, 8), ev1, 12, opp_oracle, 10, 9, 8)
         assert got == moves, opp_kind
         assert stats["draw"] == ostats["draw"] and stats["player1"] == ostats["player1"] and stats["player2"] == ostats["player2"]
+
+
+@pytest.mark.parametrize("opponent", ["network", "mcts"])
+def test_two_players_thinking_at_once_play_the_same_games(opponent):
+    """BatchedArena queues both tree players' searches before it waits for either (az_engine_search_begin / _end, the second engine
+    on a stream of its own priority: az_engine_pair); one search after the other must give the same moves, ply for ply"""
+    net, _, _ = _nets("othello", 7)
+    opp = _nets("othello", 47)[0] if opponent == "network" else "mcts"
+    runs = []
+    for overlap in (True, False):
+        arena = BatchedArena("othello", net, opponent=opp, n_sim=20, opponent_n_sim=16, seed=4, board_size=6)
+        arena.overlap = overlap
+        stats = arena.play_games(24, return_stats=True, record_moves=True)
+        runs.append(([m.tolist() for m in arena.moves], stats["draw"], stats["player1"], stats["player2"]))
+        assert all(st["error_flags"] == 0 for st in arena.engine_stats)
+    assert runs[0] == runs[1]
+
+
+def test_search_begin_and_end_come_in_pairs():
+    from alphazero_amd import engine as E
+    net, _, _ = _nets("othello", 8)
+    arena = BatchedArena("othello", net, opponent="random", n_sim=4, board_size=6)
+    eng = arena._engine(net, 4, 4, 0)
+    try:
+        board = np.zeros((4, 6, 6), np.int8)
+        board[:, 2, 2] = board[:, 3, 3] = -1
+        board[:, 2, 3] = board[:, 3, 2] = 1
+        eng.set_roots(board, np.ones(4, np.int8))
+        from alphazero_amd._lib import AzError
+        with pytest.raises(AzError):
+            eng.search_end()  # nothing begun
+        eng.search_begin(4)
+        with pytest.raises(AzError):
+            eng.search_begin(4)  # the first one is still open
+        eng.search_end()
+        with pytest.raises(ValueError):
+            eng.pair_with(eng)
+    finally:
+        eng.close()

@@ -139,3 +139,34 @@ def test_live_stage_profile():
     hnet.forward(x)
     assert hnet.profile_read()["k_heads"][1] == 5  # nothing recorded while switched off
     assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
+@pytest.mark.parametrize("tag", ["othello8", "othello6"])
+def test_fragment_order_dense_kernel_across_its_row_limits(tag):
+    """up to 1024 (fc1, K = 512) / 2048 rows (fc2, K = 1024) the dense layers run k_dense_frag (16 rows x 16 columns per wave on 16x16x4,
+    weights streamed in B-fragment order), above that the tiled GEMMs: the same boards must give the same bits on either side of
+    both limits, for row counts that do not fill the last 16-row block, and for device-side row counts below the launch's size"""
+    game, gid, H, W, A, n = TAGS[tag]
+    fx, sd, onet, _ = nets(tag)
+    hnet = E.HipNet(gid, H, W, sd, max_batch=2304)
+    assert hnet.stage_kernel(1, 1) == "k_dense_frag" and hnet.stage_kernel(2, 2048) == "k_dense_frag" and hnet.stage_kernel(2, 2049) == "k_gemm"
+    grids, players, _ = O.random_positions(gid, H, W, 21, 40, 900)
+    canon = torch.as_tensor((grids * players[:, None]).astype(np.float32), device="cuda")
+    n0 = canon.shape[0]
+    idx = (torch.arange(2304, device="cuda") * 11 + 5) % n0
+    x = canon[idx].contiguous()
+    p_ref, v_ref = hnet.forward(x)  # 2304 rows: both layers on the tiled GEMM
+    op, ov = onet.forward(x[:96].cpu().numpy())
+    assert np.array_equal(p_ref[:96].cpu().numpy(), op) and np.array_equal(v_ref[:96].cpu().numpy(), ov)
+    for B in (1, 2, 15, 16, 17, 31, 100, 129, 257, 1023, 1024, 1025, 1040, 2047, 2048, 2049):
+        p, v = hnet.forward(x[:B].contiguous())
+        assert torch.equal(p, p_ref[:B]) and torch.equal(v, v_ref[:B]), (tag, B)
+    small = E.HipNet(gid, H, W, sd, max_batch=1000)  # a launch sized for 1000 rows, the rows present a device counter
+    for count in (0, 1, 16, 17, 500, 999, 1000, 5000):
+        c = torch.tensor([count], dtype=torch.int32, device="cuda")
+        probs = torch.full((1000, A), -7.0, device="cuda")
+        v = torch.full((1000,), -7.0, device="cuda")
+        small.forward_dyn(x[:1000].contiguous(), c, probs, v)
+        m = min(count, 1000)
+        assert torch.equal(probs[:m], p_ref[:m]) and torch.equal(v[:m], v_ref[:m]), count
+        assert bool((probs[m:] == -7.0).all()) and bool((v[m:] == -7.0).all()), count
