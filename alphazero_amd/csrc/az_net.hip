@@ -507,6 +507,266 @@ __global__ __launch_bounds__(256, 2) void k_trunk(const float *__restrict__ in, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_trunk_q: ONE board per WORKGROUP of four waves, for the batches that leave most of the chip idle (a single game's search, arenas,
+// self-play waves of a few hundred games): with one wave per board the trunk is one wave's walk through ~860 dependent-issue MFMAs
+// (18-19 us whatever the batch, up to 1024 boards).  Here the board's 16x16 output tiles of every layer are dealt over the four
+// waves -- unit u = 2 mt + nt (position tile mt, channel half nt) goes to wave u % 4 --, the activations live in LDS planes the four
+// waves share, and a layer is: compute from the planes into registers, barrier (every wave has finished reading), store in place,
+// barrier.  Winograd conv2: one channel half per wave (waves 0 and 1; the 16 tiles of the board are the 16 rows of the MFMA tile and
+// cannot be split), each forming the operand transform itself.  Every output element keeps k_trunk's chain (bias, tap-major /
+// ic-minor; Winograd: the same transforms, ic ascending per frequency): identical bits.
+// ---------------------------------------------------------------------------------------------
+// one 16x16 tile of conv_mfma: positions 16 mt .. 16 mt + 15, output channels 16 nt .. 16 nt + 15 (mt, nt wave-uniform)
+template <int P_OUT, int W_OUT, int H_OUT, int IN_W, int IN_PS, int PAD>
+AZ_D f32x4 conv_tile(const float *in_lds, const float *__restrict__ wf, const float *__restrict__ bias, int lane, int mt, int nt) {
+    const int m_lane = lane & 15, kq = lane >> 4;
+    int p = 16 * mt + m_lane;
+    p = p < P_OUT ? p : P_OUT - 1;
+    const int y = p / W_OUT, x = p % W_OUT;
+    const int abase = kq * IN_PS + y * IN_W + x - PAD * (IN_W + 1);
+    unsigned vmask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        int iy = y + t / 3 - PAD, ix = x + t % 3 - PAD;
+        vmask |= (unsigned)(iy >= 0 && iy < H_OUT + 2 - 2 * PAD && ix >= 0 && ix < W_OUT + 2 - 2 * PAD) << t;
+    }
+    const float *wl = wf + 4 * lane;  // fragment i = 2 j + nt of a tap sits at [tap][i / 4][lane][i % 4]
+    float bfr[2][8];
+#define TILE_BLOAD(tap_, buf_)                                                             \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                        \
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(wl + ((tap_) * 4 + q) * 256);     \
+        bfr[buf_][2 * q] = nt ? v[1] : v[0];                                               \
+        bfr[buf_][2 * q + 1] = nt ? v[3] : v[2];                                           \
+    }
+    TILE_BLOAD(0, 0)
+    const float bv = bias[16 * nt + m_lane];
+    f32x4 acc = (f32x4){bv, bv, bv, bv};
+    float ar[A_RING];
+#define TILE_LOAD(c) in_lds[abase + ((c) / 8 / 3) * IN_W + ((c) / 8 % 3) + 4 * ((c) % 8) * IN_PS]
+#pragma unroll
+    for (int c = 0; c < A_RING; ++c) ar[c] = TILE_LOAD(c);
+#pragma unroll
+    for (int c = 0; c < 72; ++c) {
+        const int tap = c / 8, j = c % 8;
+        if (j == 0 && tap < 8) { TILE_BLOAD(tap + 1, (tap + 1) & 1) }
+        float v = ar[c % A_RING];
+        if (PAD) v = ((vmask >> tap) & 1u) ? v : 0.0f;
+        if (c + A_RING < 72) ar[c % A_RING] = TILE_LOAD(c + A_RING);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = MFMA(v, bfr[tap & 1][j], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef TILE_LOAD
+#undef TILE_BLOAD
+    return acc;
+}
+
+template <int P_OUT, int OUT_PS>
+AZ_D void store_tile_relu_lds(float *out, int lane, const f32x4 &acc, int mt, int nt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 16 * mt + (lane >> 4) * 4 + r;
+        const float v = acc[r];
+        if (m < P_OUT) out[(nt * 16 + (lane & 15)) * OUT_PS + m] = v > 0.0f ? v : 0.0f;
+    }
+}
+
+// conv2_wino for ONE channel half nt: the same patch reads, transforms and chains; yo[r][i][c] = Y[i][c] of output tile 4 (lane >> 4) + r
+// for channel 16 nt + (lane & 15), bias not yet added.  Reads only: the caller stores after the workgroup's barrier.
+template <int CH, int CW, int PS>
+AZ_D void conv2_wino_half(const float *act, const float4 *wu4, int lane, int nt, float (&yo)[4][2][2]) {
+    constexpr int TW = (CW + 1) / 2, NTL = ((CH + 1) / 2) * TW, P1 = CH * CW, RING = 3;
+    const int m = lane & 15, kq = lane >> 4;
+    const int t = m < NTL ? m : NTL - 1;
+    const int ty = t / TW, tx = t % TW;
+    const float4 *ul = wu4 + lane;
+    float cu[4][2], cw_[4][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        int off[12];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int iy = 2 * ty - 1 + a + p, ix = 2 * tx - 1 + b;
+                off[a * 4 + b] = kq * PS + ((iy >= 0 && iy < CH && ix >= 0 && ix < CW) ? iy * CW + ix : P1);
+            }
+        f32x4 acc[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) acc[f] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        float4 ub[RING][4];
+#pragma unroll
+        for (int jj = 0; jj < RING - 1; ++jj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ub[jj][q] = ul[(size_t)((p * 8 + jj) * 4 + q) * 64];
+        float d[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) d[e] = act[off[e]];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float dn[12];
+            if (j + RING - 1 < 8) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ub[(j + RING - 1) % RING][q] = ul[(size_t)((p * 8 + j + RING - 1) * 4 + q) * 64];
+            }
+            if (j + 1 < 8) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) dn[e] = act[off[e] + 4 * (j + 1) * PS];
+            }
+            float T[2][4], V[8];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (p == 0) { T[0][b] = d[b] - d[8 + b]; T[1][b] = d[4 + b] + d[8 + b]; }
+                else { T[0][b] = d[4 + b] - d[b]; T[1][b] = d[b] - d[8 + b]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                V[4 * i + 0] = T[i][0] - T[i][2]; V[4 * i + 1] = T[i][1] + T[i][2];
+                V[4 * i + 2] = T[i][2] - T[i][1]; V[4 * i + 3] = T[i][1] - T[i][3];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                const float4 u = ub[j % RING][f >> 1];
+                acc[f] = MFMA(V[f], (f & 1) ? (nt ? u.w : u.z) : (nt ? u.y : u.x), acc[f]);
+            }
+#pragma unroll
+            for (int f = 0; f < 8; ++f) asm volatile("" : "+a"(acc[f]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < 8) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) d[e] = dn[e];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float R[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                R[i][0] = (acc[4 * i + 0][r] + acc[4 * i + 1][r]) + acc[4 * i + 2][r];
+                R[i][1] = (acc[4 * i + 1][r] - acc[4 * i + 2][r]) - acc[4 * i + 3][r];
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (p == 0) { cu[r][c] = R[0][c] + R[1][c]; cw_[r][c] = R[1][c]; }
+                else { yo[r][0][c] = cu[r][c] + R[0][c]; yo[r][1][c] = (cw_[r][c] - R[0][c]) - R[1][c]; }
+            }
+        }
+    }
+}
+
+template <int CH, int CW, bool WINO>
+__global__ __launch_bounds__(256) void k_trunk_q(const float *__restrict__ in, int B, const int *__restrict__ dyn_count, TrunkParams tp, float *__restrict__ feat) {
+    using G = TrunkGeom<CH, CW>;
+    if (dyn_count) { int c = *dyn_count; B = c < B ? c : B; }
+    const int b = blockIdx.x;
+    if (b >= B) return;  // the whole workgroup: no barrier is left behind
+    __shared__ __attribute__((aligned(16))) float smem_q[G::WAVE_FLOATS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float *inp = smem_q;
+    float *act = inp + G::INP;
+    static_assert(G::P1 <= 256 && G::INP <= 256, "one element per thread");
+    const float cell = tid < G::P1 ? in[(size_t)b * G::P1 + tid] : 0.0f;  // in flight while the planes are cleared
+    if (tid < G::INP) inp[tid] = 0.0f;
+    if (WINO && tid < NCH) act[tid * G::PS + G::P1] = 0.0f;  // every plane's zero slot (Winograd patches outside the plane)
+    __syncthreads();
+    if (tid < G::P1) inp[(tid / CW + 1) * G::PW + (tid % CW) + 1] = cell;
+    __syncthreads();
+    constexpr int UPW = 2;  // units per wave: a layer has at most 2 * 4 of them (MT <= 4)
+    static_assert(G::MT2 <= 4 && G::MT3 <= 4 && G::MT4 <= 4, "at most eight 16x16 tiles per layer");
+    {   // conv1 1->32, pad 1, K = 12 (taps 9..11 carry zero weights)
+        const int m_lane = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int u = wave + 4 * i;
+            if (u < 2 * G::MT2) {
+                const int mt = u >> 1, nt = u & 1;
+                const float bv = tp.b1[16 * nt + m_lane];
+                f32x4 acc = (f32x4){bv, bv, bv, bv};
+                int p = 16 * mt + m_lane;
+                p = p < G::P1 ? p : G::P1 - 1;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    int tap = 4 * s + kq;
+                    tap = tap < 9 ? tap : 8;
+                    const float a = inp[(p / CW) * G::PW + (p % CW) + (tap / 3) * G::PW + tap % 3];
+                    acc = MFMA(a, tp.w1f[(s * 2 + nt) * 64 + lane], acc);
+                }
+                store_tile_relu_lds<G::P1, G::PS>(act, lane, acc, mt, nt);  // conv1 reads inp, writes act: no hazard
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (WINO) {  // conv2, Winograd form: waves 0 and 1 take one channel half each
+        constexpr int TW = (CW + 1) / 2, NTL = ((CH + 1) / 2) * TW;
+        float yo[4][2][2];
+        if (wave < 2) conv2_wino_half<CH, CW, G::PS>(act, reinterpret_cast<const float4 *>(tp.wu), lane, wave, yo);
+        __syncthreads();  // every read of the conv1 planes has returned
+        if (wave < 2) {
+            const int m = lane & 15, kq = lane >> 4;
+            const float bv = tp.cb[0][wave * 16 + m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tt = 4 * kq + r, y0 = 2 * (tt / TW), x0 = 2 * (tt % TW);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float v = yo[r][i][c] + bv;
+                        if (tt < NTL && y0 + i < CH && x0 + c < CW) act[(wave * 16 + m) * G::PS + (y0 + i) * CW + x0 + c] = v > 0.0f ? v : 0.0f;
+                    }
+            }
+        }
+    } else {
+        f32x4 acc[UPW];
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int u = wave + 4 * i;
+            if (u < 2 * G::MT2) acc[i] = conv_tile<G::P1, CW, CH, CW, G::PS, 1>(act, tp.wq[0], tp.cb[0], lane, u >> 1, u & 1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int u = wave + 4 * i;
+            if (u < 2 * G::MT2) store_tile_relu_lds<G::P1, G::PS>(act, lane, acc[i], u >> 1, u & 1);
+        }
+    }
+    __syncthreads();
+    {   // conv3 32->32, valid
+        f32x4 acc[UPW];
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int u = wave + 4 * i;
+            if (u < 2 * G::MT3) acc[i] = conv_tile<G::P3, G::W3, G::H3, CW, G::PS, 0>(act, tp.wq[1], tp.cb[1], lane, u >> 1, u & 1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int u = wave + 4 * i;
+            if (u < 2 * G::MT3) store_tile_relu_lds<G::P3, G::PS>(act, lane, acc[i], u >> 1, u & 1);
+        }
+    }
+    __syncthreads();
+    {   // conv4 32->32, valid -> flattened NCHW features
+        float *fo = feat + (size_t)b * (NCH * G::P4);
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int u = wave + 4 * i;
+            if (u < 2 * G::MT4) {
+                const int mt = u >> 1, nt = u & 1;
+                const f32x4 acc = conv_tile<G::P4, G::W4, G::H4, G::W3, G::PS, 0>(act, tp.wq[2], tp.cb[2], lane, mt, nt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * mt + (lane >> 4) * 4 + r;
+                    const float v = acc[r];
+                    if (m < G::P4) fo[(nt * 16 + (lane & 15)) * G::P4 + m] = v > 0.0f ? v : 0.0f;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_trunk2: the same four layers with TWO boards per wavefront on v_mfma_f32_32x32x2_f32.
 // M = the positions of both boards (tiles of 32 rows), N = the 32 output channels (one tile), K = 9 taps x 32 ic
 // walked tap-major, two input channels per MFMA (lane>>5 selects which).  Against the 16x16x4 version this
@@ -1705,7 +1965,7 @@ __global__ __launch_bounds__(64 * NT) void k_heads2(const float *__restrict__ X,
                                                     int M, int A, float *__restrict__ probs, float *__restrict__ value,
                                                     const int *__restrict__ dyn_count) {
     if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
-    constexpr int NH = NT * 16, RB = 16 * RH, XSTR = K + 2, NTHR = 64 * NT, NKB = K / 16, PF = 4;  // PF: fragment loads in flight
+    constexpr int NH = NT * 16, RB = 16 * RH, XSTR = K + 2, NTHR = 64 * NT, NKB = K / 16, PF = 4;  // PF: fragment loads in flight (8: 45.9 vs 39 us at 32768 rows, equal at 256)
     static_assert(K % 16 == 0 && NKB >= PF && RB <= NTHR && NTHR % 8 == 0, "tile plan");
     const int brow0 = blockIdx.x * RB;
     if (brow0 >= M) return;  // uniform
@@ -2551,12 +2811,19 @@ static int launch_trunk2(az_net *n, const float *in, int B, const int *dyn, hipS
 
 static bool trunk_v1() { static int v = -1; if (v < 0) { const char *e = getenv("AZ_TRUNK_V1"); v = (e && atoi(e)) ? 1 : 0; } return v == 1; }
 
+// boards up to which the trunk runs four waves per board (AZ_TRUNK_Q_MAX; 0: never)
+static int trunk_q_max() { static int v = -1; if (v < 0) { const char *e = getenv("AZ_TRUNK_Q_MAX"); v = e ? atoi(e) : 512; } return v; }
+
 template <int CH, int CW, bool WINO>
 static int launch_trunk(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
     // two boards per wave on 32x32x2 pays from ~4096 boards up (16384: 325 vs 331 us); below that the one-board-
     // per-wave kernel fills the chip better (2048: 45 vs 77 us).  AZ_TRUNK_V1=1 forces the latter.
     n->last_trunk_two_boards = (!trunk_v1() && B >= 4096) ? 1 : 0;
     if (n->last_trunk_two_boards) return launch_trunk2<CH, CW, WINO>(n, in, B, dyn, st);
+    if (B <= trunk_q_max()) {  // few boards: four waves per board (k_trunk_q)
+        hipLaunchKernelGGL((k_trunk_q<CH, CW, WINO>), dim3((unsigned)B), dim3(256), 0, st, in, B, dyn, n->tp, n->feat);
+        return AZ_OK;
+    }
     using G = TrunkGeom<CH, CW>;
     static bool attr_set = false;
     static int lds_bytes = G::LDS_BYTES;
@@ -2960,7 +3227,7 @@ extern "C" int az_net_stage_kernel(const az_net *n, int stage, int B, char *buf,
     else if (stage >= 1 && tail_is_fused(n)) name = "k_tail_small";
     else if (stage == 0) {
         const bool tuned = (n->CH == 8 && n->CW == 8) || (n->CH == 6 && n->CW == 6) || (n->CH == 7 && n->CW == 6);
-        name = (tuned && !trunk_v1() && B >= 4096) ? (use_wino(n->CH, n->CW) ? "k_trunk2<Winograd conv2>" : "k_trunk2") : "k_trunk";
+        name = (tuned && !trunk_v1() && B >= 4096) ? (use_wino(n->CH, n->CW) ? "k_trunk2<Winograd conv2>" : "k_trunk2") : ((tuned && B <= trunk_q_max()) ? "k_trunk_q" : "k_trunk");
     }
     else if (stage == 3) name = (B <= 128 && n->NH <= 128 && n->F2 % 32 == 0) ? "k_heads_small" : (n->F2 == 512 ? "k_heads2" : "k_heads");
     else {

@@ -170,3 +170,23 @@ def test_fragment_order_dense_kernel_across_its_row_limits(tag):
         m = min(count, 1000)
         assert torch.equal(probs[:m], p_ref[:m]) and torch.equal(v[:m], v_ref[:m]), count
         assert bool((probs[m:] == -7.0).all()) and bool((v[m:] == -7.0).all()), count
+
+
+@pytest.mark.parametrize("tag", ["othello8", "othello6", "connect4"])
+def test_four_waves_per_board_trunk_equals_one_wave_per_board(tag):
+    """up to 512 boards the trunk deals a board's 16x16 output tiles over the four waves of a workgroup (k_trunk_q), above that one wave
+    walks the whole board (k_trunk): same chains per output element, so the same boards give the same bits on both sides of the limit"""
+    game, gid, H, W, A, n = TAGS[tag]
+    fx, sd, onet, _ = nets(tag)
+    hnet = E.HipNet(gid, H, W, sd, max_batch=1200)
+    assert hnet.stage_kernel(0, 512) == "k_trunk_q" and hnet.stage_kernel(0, 513) == "k_trunk"
+    grids, players, _ = O.random_positions(gid, H, W, 31, 40, 1200)
+    canon = torch.as_tensor((grids * players[:, None]).astype(np.float32), device="cuda")
+    assert canon.shape[0] > 600
+    p_ref, v_ref = hnet.forward(canon)  # one wave per board
+    for B in (1, 2, 5, 64, 257, 300, 512, 513):
+        p, v = hnet.forward(canon[:B].contiguous())
+        assert torch.equal(p, p_ref[:B]) and torch.equal(v, v_ref[:B]), (tag, B)
+    op, ov = onet.forward(canon[:64].cpu().numpy())
+    p, v = hnet.forward(canon[:64].contiguous())
+    assert np.array_equal(p.cpu().numpy(), op) and np.array_equal(v.cpu().numpy(), ov)
