@@ -16,7 +16,8 @@ At N = 1 the same JSON line also carries the two single-GPU BASELINE configs at 
   config4 : Connect4 6x7, 8192 concurrent games, 200 sims/move          (BASELINE.json configs[3])
 each with games/s, examples/s and its own roofline object, `config5` (BASELINE.json configs[4]: the trainer loop on Othello 8x8,
 per-phase seconds) and `cpu_baseline`: the CPU oracle (C port of the reference's self-play loop) timed on the host cores with the
-protocol of BASELINE.md section 3.  At N > 1 the line carries `config3` (BASELINE.json configs[2] at its LITERAL size: 32768
+protocol of BASELINE.md section 3, and `latency`: the shapes the reference itself is used in (one game's search, self-play waves of 64
+and 512 games, an evaluation arena of 64 games), where a lock-step is five dependent launches on an almost empty chip.  At N > 1 the line carries `config3` (BASELINE.json configs[2] at its LITERAL size: 32768
 concurrent games sharded N ways, RCCL sample all-gather) and `config5` over all ranks.
 
 How to read `roofline` (every field can be recomputed from profiles/ + the fields beside it):
@@ -512,6 +513,43 @@ def run_config5(job, episodes, sims, eval_episodes=64, variants=None):
     return out
 
 
+def run_latency(sims):
+    """The reference's own shapes of use, where nothing fills the chip and a lock-step is a chain of five dependent launches: one game's
+    search (MCT.search behind AlphaZeroPlayer.get_move, players.py:158-191), small self-play waves, and an evaluation arena of 64 games
+    against another network (trainer.py:408-446) with the two players' searches overlapped."""
+    import numpy as np
+    from alphazero_amd import engine as E
+    from alphazero_amd.arena import BatchedArena
+    from alphazero_amd.games.othello import OthelloNet
+    torch.manual_seed(0)
+    net, net2 = OthelloNet(n=8).cuda().eval(), OthelloNet(n=8).cuda().eval()
+    out = {"workload": f"Othello 8x8, {sims} sims/move, random-init OthelloNet", "self_play_waves": {}}
+    for G in (1, 64, 512):
+        hnet = net.to_hip(max_batch=G)
+        eng = E.SelfPlayEngine(0, 8, 8, n_slots=G, n_sim=sims, net=hnet, seed=0)
+        eng.run(G)  # warm-up: kernels loaded, graph captured
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        smp = eng.run(G, first_game_id=G)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = eng.stats()
+        out["self_play_waves"][str(G)] = {"games_per_sec": G / dt, "seconds": dt, "us_per_lockstep": 1e6 * dt / max(1, st["lockstep_iters"]),
+                                          "ms_per_move": 1e3 * dt / (int(smp["z"].shape[0]) / G)}
+        eng.close()
+        hnet.close()
+    for overlap in (True, False):
+        ar = BatchedArena("othello", net, opponent=net2, n_sim=sims, seed=1, board_size=8)
+        ar.overlap = overlap
+        ar.play_games(64, shard=False)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ar.play_games(64, shard=False)
+        torch.cuda.synchronize()
+        out["arena_64_games_vs_network_seconds" + ("" if overlap else "_one_player_after_the_other")] = time.perf_counter() - t0
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -608,6 +646,8 @@ def main():
             out["config4"] = run_single("config4", "connect4", 8192, 200, steps=2, warmup=1, waves=8)
         if config5 is not None:
             out["config5"] = config5
+        if world == 1 and not args.no_literal_configs:
+            out["latency"] = run_latency(args.sims)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
