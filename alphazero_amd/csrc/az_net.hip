@@ -1742,19 +1742,16 @@ __global__ __launch_bounds__(64 * NT) void k_dense_frag(const float *__restrict_
 #pragma unroll
     for (int p = 0; p < PF; ++p) bq[p] = wq[(size_t)p * wstep];  // in flight while the rows are staged
     const float bv = bias[ct * 16 + m];
-    {   // the block's 16 rows -> LDS (rows past M repeat the last row: finite operands, never stored); K % 64 == 0
-        const int kv = K / 4, nv = 16 * kv;
+    {   // the block's rows -> LDS; K % 64 == 0.  Rows past M are not staged at all (a single game's search fills ONE of the 16): what the
+        // MFMAs then read for them is whatever the LDS holds -- every output row depends on its own A row only, and those rows are never stored
+        const int kv = K / 4, rows = (M - brow0) < 16 ? (M - brow0) : 16, nv = rows * kv;
         for (int q0 = 0; q0 < nv; q0 += 4 * NTHR) {
             float4 rx[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int q = q0 + tid + NTHR * i;
                 rx[i] = make_float4(0, 0, 0, 0);
-                if (q < nv) {
-                    int row = brow0 + q / kv;
-                    row = row < M ? row : M - 1;
-                    rx[i] = reinterpret_cast<const float4 *>(X + (size_t)row * K)[q % kv];
-                }
+                if (q < nv) rx[i] = reinterpret_cast<const float4 *>(X + (size_t)(brow0 + q / kv) * K)[q % kv];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1965,7 +1962,7 @@ __global__ __launch_bounds__(64 * NT) void k_heads2(const float *__restrict__ X,
                                                     int M, int A, float *__restrict__ probs, float *__restrict__ value,
                                                     const int *__restrict__ dyn_count) {
     if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
-    constexpr int NH = NT * 16, RB = 16 * RH, XSTR = K + 2, NTHR = 64 * NT, NKB = K / 16, PF = 4;  // PF: fragment loads in flight (8: 45.9 vs 39 us at 32768 rows, equal at 256)
+    constexpr int NH = NT * 16, RB = 16 * RH, XSTR = K + 2, NTHR = 64 * NT, NKB = K / 16, PF = 4;  // PF: fragment loads in flight (8: 45.9 vs 39 us at 32768 rows; 16 at <= 1024 rows: no faster)
     static_assert(K % 16 == 0 && NKB >= PF && RB <= NTHR && NTHR % 8 == 0, "tile plan");
     const int brow0 = blockIdx.x * RB;
     if (brow0 >= M) return;  // uniform
@@ -1982,23 +1979,21 @@ __global__ __launch_bounds__(64 * NT) void k_heads2(const float *__restrict__ X,
 #pragma unroll
     for (int p = 0; p < PF; ++p) bq[p] = wq[(size_t)p * NT * 64];
     const float bv = bh[wave * 16 + m];
-    {   // the block's rows of X -> LDS (rows past M repeat the last row: finite operands, never stored)
+    {   // the block's rows of X -> LDS.  Rows past M are not staged (their logits come out of whatever the LDS holds and are never stored:
+        // an output row depends on its own A row only)
         constexpr int NV = RB * K / 4, C = (NV + NTHR - 1) / NTHR;
+        const int nv = ((M - brow0) < RB ? (M - brow0) : RB) * (K / 4);
         float4 rx[C];
 #pragma unroll
         for (int i = 0; i < C; ++i) {
             const int q = tid + NTHR * i;
             rx[i] = make_float4(0, 0, 0, 0);
-            if (NV % NTHR == 0 || q < NV) {
-                int row = brow0 + q / (K / 4);
-                row = row < M ? row : M - 1;
-                rx[i] = reinterpret_cast<const float4 *>(X + (size_t)row * K)[q % (K / 4)];
-            }
+            if (q < nv) rx[i] = reinterpret_cast<const float4 *>(X + (size_t)(brow0 + q / (K / 4)) * K)[q % (K / 4)];
         }
 #pragma unroll
         for (int i = 0; i < C; ++i) {
             const int q = tid + NTHR * i;
-            if (NV % NTHR == 0 || q < NV) {
+            if (q < nv) {
                 float *d = Xs + (q / (K / 4)) * XSTR + 4 * (q % (K / 4));  // 8-byte aligned (XSTR is even)
                 *reinterpret_cast<float2 *>(d) = make_float2(rx[i].x, rx[i].y);
                 *reinterpret_cast<float2 *>(d + 2) = make_float2(rx[i].z, rx[i].w);
@@ -2251,6 +2246,104 @@ __global__ __launch_bounds__(256) void k_tail_small(const float *__restrict__ fe
         if (row0 + r < M) {
             if (lane < A) probs[(size_t)(row0 + r) * A + lane] = e / s;
             if (lane == 0) value[row0 + r] = az_det_tanhf(vl);
+        }
+    }
+}
+
+// k_tail_mfma: the same three layers on v_mfma_f32_16x16x4_f32.  k_tail_small walks every row's 192 + 64 + 32 dependent fmas and first
+// copies all three weight matrices (58 KB) into LDS for its 16 rows; here a workgroup's 16 rows are ONE MFMA row tile, fc1's four column
+// tiles go to the four waves (a chain of 48 MFMAs each), fc2's two to waves 0 and 1 (16 MFMAs), the heads' one to wave 0 (8), the
+// activations pass through LDS between the layers and the weights come straight from L2 in B-fragment layout (lane (n, kq) reads
+// W[4 ks + kq][n0 + n]: 64-byte runs of the row-major matrix), all requested before the first barrier.  Same chains (bias, then k
+// ascending), same softmax arithmetic (exact maximum, az_det_expf, the sum in ascending action order, e / S; az_det_tanhf): identical bits.
+template <int FIN, int F1, int F2, int NH, int A>
+__global__ __launch_bounds__(256) void k_tail_mfma(const float *__restrict__ feat, const float *__restrict__ W1, const float *__restrict__ b1,
+                                                   const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ Wh,
+                                                   const float *__restrict__ bh, int M, float *__restrict__ probs, float *__restrict__ value,
+                                                   const int *__restrict__ dyn_count) {
+    static_assert(F1 == 64 && F2 == 32 && NH == 16 && A < NH && FIN % 16 == 0, "four / two / one column tiles for the four waves");
+    if (dyn_count) { int c = *dyn_count; M = c < M ? c : M; }
+    const int brow0 = blockIdx.x * 16;
+    if (brow0 >= M) return;  // uniform for the workgroup
+    constexpr int XS = FIN + 4, H1S = F1 + 4, H2S = F2 + 4, LS = NH + 1;  // row strides = 4 mod 64 banks (fragment reads conflict-free)
+    __shared__ __attribute__((aligned(16))) float xs[16 * XS];
+    __shared__ __attribute__((aligned(16))) float h1s[16 * H1S];
+    __shared__ __attribute__((aligned(16))) float h2s[16 * H2S];
+    __shared__ float lgs[16 * LS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+    // the block's rows: 16 x FIN / 4 float4
+    constexpr int NX = 16 * FIN / 4, CX = (NX + 255) / 256;
+    float4 rx[CX];
+#pragma unroll
+    for (int i = 0; i < CX; ++i) {
+        const int q = tid + 256 * i;
+        rx[i] = make_float4(0, 0, 0, 0);
+        if (q < NX) {
+            int row = brow0 + q / (FIN / 4);
+            row = row < M ? row : M - 1;
+            rx[i] = reinterpret_cast<const float4 *>(feat + (size_t)row * FIN)[q % (FIN / 4)];
+        }
+    }
+    // this wave's weight fragments of all three layers, requested now (their latency runs under the row staging)
+    float w1f[FIN / 4], w2f[F1 / 4], whf[F2 / 4];
+#pragma unroll
+    for (int ks = 0; ks < FIN / 4; ++ks) w1f[ks] = W1[(size_t)(4 * ks + kq) * F1 + 16 * wave + m];
+    if (wave < 2) {
+#pragma unroll
+        for (int ks = 0; ks < F1 / 4; ++ks) w2f[ks] = W2[(size_t)(4 * ks + kq) * F2 + 16 * wave + m];
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int ks = 0; ks < F2 / 4; ++ks) whf[ks] = Wh[(size_t)(4 * ks + kq) * NH + m];
+    }
+    const float bv1 = b1[16 * wave + m], bv2 = wave < 2 ? b2[16 * wave + m] : 0.0f, bvh = bh[m];
+#pragma unroll
+    for (int i = 0; i < CX; ++i) {
+        const int q = tid + 256 * i;
+        if (q < NX) *reinterpret_cast<float4 *>(xs + (q / (FIN / 4)) * XS + 4 * (q % (FIN / 4))) = rx[i];
+    }
+    __syncthreads();
+    {   // fc1: column tile `wave`
+        f32x4 acc = (f32x4){bv1, bv1, bv1, bv1};
+        const float *xa = xs + m * XS + kq;
+#pragma unroll
+        for (int ks = 0; ks < FIN / 4; ++ks) acc = MFMA(xa[4 * ks], w1f[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1s[(4 * kq + r) * H1S + 16 * wave + m] = acc[r] > 0.0f ? acc[r] : 0.0f;  // C layout: row 4 kq + r, column m
+    }
+    __syncthreads();
+    if (wave < 2) {  // fc2
+        f32x4 acc = (f32x4){bv2, bv2, bv2, bv2};
+        const float *ha = h1s + m * H1S + kq;
+#pragma unroll
+        for (int ks = 0; ks < F1 / 4; ++ks) acc = MFMA(ha[4 * ks], w2f[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2s[(4 * kq + r) * H2S + 16 * wave + m] = acc[r] > 0.0f ? acc[r] : 0.0f;
+    }
+    __syncthreads();
+    if (wave == 0) {  // heads: logits | value | padding
+        f32x4 acc = (f32x4){bvh, bvh, bvh, bvh};
+        const float *ha = h2s + m * H2S + kq;
+#pragma unroll
+        for (int ks = 0; ks < F2 / 4; ++ks) acc = MFMA(ha[4 * ks], whf[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lgs[(4 * kq + r) * LS + m] = acc[r];
+    }
+    __syncthreads();
+    if (tid < 16) {  // one lane per row: the arithmetic of k_tail_small / k_heads, action for action
+        const int row = brow0 + tid;
+        const float *l = lgs + tid * LS;
+        float mx = l[0];
+#pragma unroll
+        for (int a = 1; a < A; ++a) mx = fmaxf(mx, l[a]);
+        float e[A];
+        float sum = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) { e[a] = az_det_expf(l[a] - mx); sum += e[a]; }
+        if (row < M) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) probs[(size_t)row * A + a] = e[a] / sum;
+            value[row] = az_det_tanhf(l[A]);
         }
     }
 }
@@ -3002,8 +3095,17 @@ static int heads2_go(az_net *n, int B, float *probs, float *value, const int *dy
     return AZ_OK;
 }
 
+// rows up to which the row-per-workgroup heads kernel runs: 128 where k_heads2 has no instantiation; never for OthelloNet (F2 = 512), whose
+// k_heads2 is faster at every size (8.6 vs 9.8 us at one row, 9.6 vs 10.3 at 128).  AZ_HEADS_SMALL_MAX forces a limit for A/B runs.
+static int heads_small_max(const az_net *n) {
+    static int v = -2;
+    if (v == -2) { const char *e = getenv("AZ_HEADS_SMALL_MAX"); v = e ? atoi(e) : -1; }
+    if (v >= 0) return v;
+    return (n->F2 == 512 && (n->NH == 80 || n->NH == 48)) ? 0 : 128;
+}
+
 static int launch_heads(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
-    if (B <= 128 && n->NH <= 128 && n->F2 % 32 == 0) {  // few rows: latency, not throughput
+    if (B <= heads_small_max(n) && n->NH <= 128 && n->F2 % 32 == 0) {  // few rows: latency, not throughput
         hipLaunchKernelGGL(k_heads_small, dim3((unsigned)B), dim3(128), 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, n->NH, probs, value, dyn);
         return AZ_OK;
     }
@@ -3024,6 +3126,9 @@ static int launch_heads(az_net *n, int B, float *probs, float *value, const int 
         default: az_set_error("no heads kernel for padded width %d", n->NH); return AZ_EINVAL;
     }
 }
+
+// AZ_TAIL_V1=1: the fma kernel of the rounds before (k_tail_small) instead of k_tail_mfma, for A/B runs
+static bool tail_v1() { static int v = -1; if (v < 0) { const char *e = getenv("AZ_TAIL_V1"); v = (e && atoi(e)) ? 1 : 0; } return v == 1; }
 
 // fc1 + fc2 + heads as ONE launch where the dense layers are small (Connect4Net); returns false when no instantiation fits
 static bool tail_is_fused(const az_net *n) {
@@ -3047,6 +3152,11 @@ static int tail_go(az_net *n, int B, float *probs, float *value, const int *dyn,
 }
 
 static int launch_tail(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
+    if (!tail_v1()) {
+        hipLaunchKernelGGL((k_tail_mfma<192, 64, 32, 16, 7>), dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, n->feat, n->fc1w, n->fc1b, n->fc2w,
+                           n->fc2b, n->hw, n->hb, B, probs, value, dyn);
+        return AZ_OK;
+    }
     static int r8 = -1;
     if (r8 < 0) { const char *e = getenv("AZ_TAIL_R8_FROM"); r8 = e ? atoi(e) : 0x7fffffff; }
     // 16 rows per workgroup (measured: 9.3 us up to 4096 rows, 12.7 us at 8192; 32 rows per workgroup: 19 us at every size)
@@ -3224,12 +3334,12 @@ extern "C" int az_net_stage_kernel(const az_net *n, int stage, int B, char *buf,
     AZ_REQUIRE(n && buf && cap > 0 && stage >= 0 && stage <= 3 && B > 0, AZ_EINVAL, "bad arguments");
     const char *name = "";
     if (n->game == AZ_TICTACTOE) name = "k_mlp";
-    else if (stage >= 1 && tail_is_fused(n)) name = "k_tail_small";
+    else if (stage >= 1 && tail_is_fused(n)) name = tail_v1() ? "k_tail_small" : "k_tail_mfma";
     else if (stage == 0) {
         const bool tuned = (n->CH == 8 && n->CW == 8) || (n->CH == 6 && n->CW == 6) || (n->CH == 7 && n->CW == 6);
         name = (tuned && !trunk_v1() && B >= 4096) ? (use_wino(n->CH, n->CW) ? "k_trunk2<Winograd conv2>" : "k_trunk2") : ((tuned && B <= trunk_q_max()) ? "k_trunk_q" : "k_trunk");
     }
-    else if (stage == 3) name = (B <= 128 && n->NH <= 128 && n->F2 % 32 == 0) ? "k_heads_small" : (n->F2 == 512 ? "k_heads2" : "k_heads");
+    else if (stage == 3) name = (B <= heads_small_max(n) && n->NH <= 128 && n->F2 % 32 == 0) ? "k_heads_small" : (n->F2 == 512 ? "k_heads2" : "k_heads");
     else {
         const int N = stage == 1 ? n->F1 : n->F2, K = stage == 1 ? n->FIN : n->F1;
         switch (gemm_kind(B, N, K, (stage == 1 ? n->fc1wq : n->fc2wq) != nullptr)) {

@@ -247,7 +247,7 @@ class Workload:
         ov = self.hnet.profile_overhead_ms()  # an event-to-event interval costs this much with no kernel in it
         self.hnet.profile(False)
         fl, by = stage_flops(*self.geom), algorithmic_bytes(*self.geom)
-        fused_tail = self.game == "connect4"  # fc1 + fc2 + heads are one fused launch (k_tail_small), booked in the fc1 slot
+        fused_tail = self.game == "connect4"  # fc1 + fc2 + heads are one fused launch (k_tail_mfma), booked in the fc1 slot
         evals = st["net_evals"]
         raw = {k: prof[k][0] for k in SLOTS}
         cnt = {k: prof[k][1] for k in SLOTS}
@@ -311,7 +311,7 @@ class Workload:
             roof["end_to_end_frac"] = timed_evals * sum(fl) / timed_seconds / 1e12 / PEAK_F32_MFMA_TFLOPS
             roof["end_to_end_tflops"] = timed_evals * sum(fl) / timed_seconds / 1e12
         if fused_tail:
-            roof["note"] = "Connect4Net: fc1 + fc2 + heads run as ONE fused launch (k_tail_small), booked under 'dense'"
+            roof["note"] = "Connect4Net: fc1 + fc2 + heads run as ONE fused launch (k_tail_mfma), booked under 'dense'"
         return roof
 
     def close(self):

@@ -41,7 +41,7 @@ def classify(name, game, grid=None):
         return "k_trunk"
     if "k_heads" in name:
         return "k_heads"
-    if "k_tail_small" in name:
+    if "k_tail_small" in name or "k_tail_mfma" in name:
         return "k_tail"
     if "k_gemm" in name or "k_dense" in name:
         kt = re.search(r"k_gemm<[^>]*,\s*(\d+)>", name)
