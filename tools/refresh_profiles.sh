@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the MI355X box (gpurun): counter passes, bench line, rocprofv3 kernel stats of the same command.
-# usage: tools/refresh_profiles.sh TAG [all|net|kstep|bench|train]   -> gpurun_out/TAG_*  (tools/collect_profiles.py condenses; copy into profiles/)
+# usage: tools/refresh_profiles.sh TAG [all|net|kstep|bench|train|latency]   -> gpurun_out/TAG_*  (tools/collect_profiles.py condenses; copy into profiles/)
 # Counter passes first (bench.py reads profiles/traffic.json, mfma_counters.json, kstep_counters.json).  Every pass is
 # its own rocprofv3 run with --kernel-trace only (no --stats, no other trace domain), the program directly after `--`.
 set -o pipefail
@@ -12,7 +12,7 @@ pass() {  # name, counters, program args...
   local name=$1 ctr=$2; shift 2
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${TAG}_$name -o k -- python3 "$@" > $OUT/${TAG}_$name.log 2>&1 || echo "pass $name failed (see $OUT/${TAG}_$name.log)"
 }
-ONLY=${2:-all}   # all | net | kstep | bench | train
+ONLY=${2:-all}   # all | net | kstep | bench | train | latency
 if [ $ONLY = all ] || [ $ONLY = net ]; then
 for W in "othello 32768" "othello 4096" "connect4 8192"; do
   set -- $W; g=$1; b=$2
@@ -54,6 +54,18 @@ for W in "othello8 64 500" "othello8 512 200" "connect4 64 500" "tictactoe 64 50
   f=$(find $OUT/${TAG}_prof_train_$1_$2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_train_$1_$2_kernel_stats.csv
   rm -rf $OUT/${TAG}_prof_train_$1_$2
 done
+fi
+if [ $ONLY = all ] || [ $ONLY = latency ]; then
+# the latency regime: rocprofv3 stats of a one-game wave, a 64-game wave (k_trunk_q, k_dense_frag, k_heads2, k_step) and stage times over row counts
+cd /tmp
+for G in 1 64; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_lat_$G -o k -- python3 $R/tools/run_config.py othello $G > $OUT/${TAG}_lat_$G.log 2>&1
+  f=$(find $OUT/${TAG}_prof_lat_$G -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_lat_${G}_kernel_stats.csv
+  rm -rf $OUT/${TAG}_prof_lat_$G
+done
+cd $R
+python3 tools/dense_bench.py 1 64 256 512 1024 2048 4096 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_stage_times.txt
+python3 tools/stage_bench.py connect4 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_stage_times.txt
 fi
 cd $R
 python3 tools/collect_profiles.py $TAG
