@@ -123,6 +123,14 @@ AZ_D double az_det_exp(double x) {
     return p * __longlong_as_double((long long)((u64)(ki + 1023) << 52));
 }
 
+// N ** (1 / temp) of get_action_probs (mcts.py:114-116) for temperatures other than 0 and 1: exp(log(n) * inv_temp) on the fixed
+// polynomials above, so that the GPU and the CPU oracle (orc_det_pow) produce the same bits; within 1e-13 relative of libm's pow
+// for the visit counts and temperatures a schedule can produce (tests/test_oracle_mct.py pins it against the reference's pi).
+AZ_D double az_det_pow(double n, double inv_temp) {
+    if (!(n > 0.0)) return 0.0;
+    return az_det_exp(az_det_log(n) * inv_temp);
+}
+
 struct Philox4 { u32 x, y, z, w; };
 
 AZ_D Philox4 az_philox(u32 k0, u32 k1, u32 c0, u32 c1, u32 c2, u32 c3) {

@@ -783,10 +783,11 @@ __global__ void k_move(EngDev E) {
         chosen = fc + pick;
         if (si >= 0) pi[pool[chosen].act] = 1.0f;
     } else {
+        const double inv_temp = 1.0 / temp;
         double sum = 0.0;
         for (int i = 0; i < nc; ++i) {
             double n = (double)pool[fc + i].N;
-            sum += (temp == 1.0) ? n : pow(n, 1.0 / temp);
+            sum += (temp == 1.0) ? n : az_det_pow(n, inv_temp);
         }
         double u = 2.0, cum = 0.0;
         if (nc > 1) {
@@ -796,7 +797,7 @@ __global__ void k_move(EngDev E) {
         int last = 0; bool found = false;
         for (int i = 0; i < nc; ++i) {
             double n = (double)pool[fc + i].N;
-            double p = ((temp == 1.0) ? n : pow(n, 1.0 / temp)) / sum;
+            double p = ((temp == 1.0) ? n : az_det_pow(n, inv_temp)) / sum;
             if (si >= 0) pi[pool[fc + i].act] = (float)p;
             if (p > 0.0) last = i;
             cum += p;

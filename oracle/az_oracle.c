@@ -106,6 +106,14 @@ double orc_det_exp(double x) {
     return p * bits_to_d((uint64_t)(ki + 1023) << 52);
 }
 
+/* node.N ** (1. / temp) of MCT.get_action_probs (mcts.py:114-116) for temperatures other than 0 and 1, as the HIP engine computes
+ * it (az_det_pow, csrc/az_device.h): exp(log(n) * inv_temp) on the fixed polynomials above -- the same bits on both sides; the
+ * distance to libm's pow (what the reference calls) is pinned by tests/test_oracle_mct.py::test_det_pow_against_libm. */
+double orc_det_pow(double n, double inv_temp) {
+    if (!(n > 0.0)) return 0.0;
+    return orc_det_exp(orc_det_log(n) * inv_temp);
+}
+
 void orc_philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                     uint32_t out[4]) {
     for (int r = 0; r < 10; ++r) {
@@ -1047,9 +1055,10 @@ int orc_mct_choose(orc_mct *t, const orc_board *rootb, double temp, double *pi, 
         return t->nodes[c].action;
     }
     double val[ORC_MAX_ACTIONS], sum = 0.0; /* mcts.py:114-116 */
+    const double inv_temp = 1.0 / temp;
     for (int i = 0; i < k; ++i) {
         double n = (double)t->nodes[r->first_child + i].N;
-        val[i] = temp == 1.0 ? n : pow(n, 1.0 / temp);
+        val[i] = temp == 1.0 ? n : orc_det_pow(n, inv_temp);
         sum += val[i];
     }
     for (int i = 0; i < k; ++i) pi[t->nodes[r->first_child + i].action] = val[i] / sum;

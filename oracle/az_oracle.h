@@ -98,6 +98,7 @@ float orc_det_expf(float x);
 float orc_det_tanhf(float x);
 double orc_det_log(double x);
 double orc_det_exp(double x);
+double orc_det_pow(double n, double inv_temp);
 void orc_philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                     uint32_t out[4]);
 

@@ -103,6 +103,8 @@ def lib():
     L.orc_det_log.restype = C.c_double
     L.orc_det_exp.argtypes = [C.c_double]
     L.orc_det_exp.restype = C.c_double
+    L.orc_det_pow.argtypes = [C.c_double, C.c_double]
+    L.orc_det_pow.restype = C.c_double
     L.orc_philox4x32.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
     L.orc_mct_create.argtypes = [C.POINTER(MctCfg)]
     L.orc_mct_create.restype = C.c_void_p

@@ -66,10 +66,13 @@ def test_mct_fixture(tag):
         eng.close()
 
 
+@pytest.mark.parametrize("name", ["selfplay", "selfplay_frac"])
 @pytest.mark.parametrize("tag", MCT_TAGS)
-def test_selfplay_fixture(tag):
+def test_selfplay_fixture(tag, name):
+    """G4 on the GPU; `selfplay_frac` = the reference's self_play under temp_max_step 2 / temp_min_step 6: plies 3-5 at
+    tau = 0.75 / 0.5 / 0.25 (N ** (1 / tau), mcts.py:114-116 -> az_det_pow in k_move)"""
     game, gid, H, W, A, n = TAGS[tag]
-    fx = golden(f"selfplay_{tag}.npz")
+    fx = golden(f"{name}_{tag}.npz")
     names = [str(x) for x in fx["transf_names"]]
     orig = fx["transformation"] == names.index("None")
     eng = E.SelfPlayEngine(gid, H, W, n_slots=2, n_sim=int(fx["sims"]), dirichlet_alpha=float(fx["alpha"]),
@@ -97,6 +100,30 @@ def test_production_mode_equals_oracle_fakenet(tag, n_games, n_sim, slots):
     assert st["games_done"] == n_games and st["samples"] == len(ref["z"]) and st["net_evals"] == ref["n_evals"]
     for k in ("state", "z", "meta", "visits", "pi"):
         assert np.array_equal(got[k], ref[k]), k
+
+
+@pytest.mark.parametrize("tag,n_games,n_sim,tmax,tmin", [("othello8", 48, 40, 2, 8), ("othello6", 64, 30, 15, 20), ("connect4", 96, 50, 1, 7),
+                                                         ("tictactoe", 128, 30, 0, 5)])
+def test_production_mode_fractional_temperatures_equal_oracle(tag, n_games, n_sim, tmax, tmin):
+    """temp_max_step < temp_min_step - 1 (the reference's base defaults are 15 / 20, base.py:70-72): the plies in between are
+    played at fractional temperatures -- pi = N ** (1 / tau) / sum through az_det_pow on the GPU and orc_det_pow on the CPU, the
+    move drawn from it: samples, policies and moves bit-equal, random ties and Philox noise on"""
+    game, gid, H, W, A, n = TAGS[tag]
+    eng = E.SelfPlayEngine(gid, H, W, n_slots=32, n_sim=n_sim, evaluator=E.EVAL_FAKE, seed=13, node_capacity=32768,
+                           temp_max_step=tmax, temp_min_step=tmin, sample_capacity=n_games * (2 * H * W))
+    got = sort_samples(eng.run(n_games, first_game_id=500))
+    ref = O.selfplay(gid, H, W, n_games, n_sim, ("fake", None), seed=13, first_game_id=500, temp_max_step=tmax, temp_min_step=tmin)
+    for k in ("state", "z", "meta", "visits", "pi"):
+        assert np.array_equal(got[k], ref[k]), k
+    ply = got["meta"][:, 1]
+    frac = (ply > tmax) & (ply < tmin)
+    vis = got["visits"][frac].astype(np.float64)
+    tau = 1.0 - (ply[frac] - tmax) / (tmin - tmax)
+    want = vis ** (1.0 / tau)[:, None]
+    want /= want.sum(1, keepdims=True)
+    assert frac.sum() > n_games and np.abs(got["pi"][frac] - want).max() < 1e-7  # pi is stored as float32
+    many = (vis > 0).sum(1) > 1
+    assert many.any() and not np.allclose(got["pi"][frac][many], (vis / vis.sum(1, keepdims=True))[many])
 
 
 def test_capacity_errors_are_loud():

@@ -86,8 +86,9 @@ def test_committed_fixtures_are_what_the_reference_produces(R, tag, n_games, n_p
     gen_golden.gen_net(R, tag, positions)
     gen_golden.gen_mct(R, tag, positions)
     gen_golden.gen_selfplay(R, tag, *sp)
+    gen_golden.gen_selfplay(R, tag, *sp, seed=11, temp_steps=(2, 6), name="selfplay_frac")  # fractional temperatures
     gen_golden.gen_sgd(R, tag)  # G6: the reference's optimize_network on the memory just regenerated
-    for kind in ("rules", "net", "mct", "selfplay", "sgd"):
+    for kind in ("rules", "net", "mct", "selfplay", "selfplay_frac", "sgd"):
         name = f"{kind}_{tag}.npz"
         new = np.load(os.path.join(tmp_path, name), allow_pickle=False)
         old = np.load(os.path.join(os.path.dirname(__file__), "golden", name), allow_pickle=False)

@@ -117,6 +117,31 @@ def test_temperature_one_move_sampling_follows_the_visit_distribution():
     assert stats.chi2_contingency(np.stack([counts[sup], ref[sup]]))[1] > 1e-3
 
 
+@pytest.mark.parametrize("tau", [0.75, 0.5, 0.25])
+def test_fractional_temperature_move_sampling_follows_the_powered_visit_distribution(tau):
+    """0 < tau < 1 (linear schedule between temp_max_step and temp_min_step, schedulers.py:33-40): the move is drawn with
+    probability N ** (1 / tau) / sum (mcts.py:114-116, players.py:188-189)"""
+    b = O.new_board(O.OTHELLO, 8, 8)
+    n = 8000
+    counts, pi_ref = np.zeros(65, np.int64), None
+    for g in range(n):
+        t = O.MCT(("fake", None), tie_mode=O.TIE_LOWEST, noise_mode=O.NOISE_OFF, seed=9, game_id=g)
+        t.search(b, 60)
+        act, pi, vis = t.choose(b, tau)
+        if pi_ref is None:
+            pi_ref = pi.copy()
+            want = vis.astype(np.float64) ** (1.0 / tau)
+            assert np.abs(pi - want / want.sum()).max() < 1e-13 and abs(pi.sum() - 1) < 1e-12
+        assert np.array_equal(pi, pi_ref)
+        counts[act] += 1
+    sup = pi_ref > 0
+    assert counts[~sup].sum() == 0 and sup.sum() == 4
+    assert stats.chisquare(counts[sup], n * pi_ref[sup]).pvalue > 1e-3, (counts[sup], n * pi_ref[sup])
+    ref = np.bincount(np.random.RandomState(4).choice(65, size=n, p=pi_ref), minlength=65)
+    seen = sup & (counts + ref > 0)  # at tau = 0.25 the rarest move has p ~ 1e-5: a column neither generator ever draws
+    assert stats.chi2_contingency(np.stack([counts[seen], ref[seen]]))[1] > 1e-3
+
+
 def test_gamma_sampler_exhaustion_is_reported():
     """the 64-attempt cap of the Marsaglia-Tsang loop cannot be reached in practice (p < 1e-38 per draw): it is an error
     flag on both sides (oracle: search fails; engine: ERR_RNG -> AZ_ESTATE), never a silent g = d.  Here: the draws of

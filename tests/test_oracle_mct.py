@@ -57,11 +57,19 @@ def test_mct_fixture(tag):
     assert checked == n_rec and checked > 100
 
 
+@pytest.mark.parametrize("name", ["selfplay", "selfplay_frac"])
 @pytest.mark.parametrize("tag", MCT_TAGS)
-def test_selfplay_fixture(tag):
-    """AlphaZeroTrainer.self_play (trainer.py:215-273) sample stream, un-augmented part."""
+def test_selfplay_fixture(tag, name):
+    """AlphaZeroTrainer.self_play (trainer.py:215-273) sample stream, un-augmented part.  `selfplay_frac`: the same under
+    temp_max_step = 2, temp_min_step = 6 -- plies 3, 4, 5 are played at tau = 0.75, 0.5, 0.25, where the reference's pi is
+    N ** (1 / tau) / sum (mcts.py:114-116, schedulers.py:33-40) and the oracle's is orc_det_pow."""
     game, gid, H, W, A, n = TAGS[tag]
-    fx = golden(f"selfplay_{tag}.npz")
+    fx = golden(f"{name}_{tag}.npz")
+    if name == "selfplay_frac":
+        assert (int(fx["temp_max_step"]), int(fx["temp_min_step"])) == (2, 6)
+        frac = (fx["move_idx"] > 2) & (fx["move_idx"] < 6) & (fx["transformation"] == [str(x) for x in fx["transf_names"]].index("None"))
+        # the fixture does hold fractional-temperature policies: neither one-hot nor proportional to the visits alone
+        assert frac.sum() >= 3 * int(fx["episodes"]) - 3 and ((fx["pi"][frac] > 0) & (fx["pi"][frac] < 1)).sum() > frac.sum()
     names = [str(x) for x in fx["transf_names"]]
     orig = fx["transformation"] == names.index("None")
     r = O.selfplay(gid, H, W, int(fx["episodes"]), int(fx["sims"]), ("fake", None), alpha=float(fx["alpha"]),
@@ -75,6 +83,25 @@ def test_selfplay_fixture(tag):
     assert np.array_equal(r["meta"][:, 1], fx["move_idx"][orig])
     assert np.all(fx["player"] == 1)
     assert np.abs(r["pi"].astype(np.float64) - fx["pi"][orig]).max() < 1e-7  # pi is stored as float32
+
+
+def test_det_pow_against_libm():
+    """orc_det_pow (= az_det_pow of the HIP engine, bit for bit) against the pow the reference calls (Python float ** float =
+    libm): relative distance below 1e-13 for every visit count up to 2000 and every temperature a linear schedule produces
+    with up to 64 steps between temp_max_step and temp_min_step; exact at the edges (0 visits -> 0, tau = 1 is not routed here)"""
+    L = O.lib()
+    worst = 0.0
+    for tmax, tmin in [(2, 6), (15, 20), (0, 3), (1, 50), (0, 64)]:
+        for step in range(tmax + 1, tmin):
+            t = 1 - (step - tmax) / (tmin - tmax)
+            for n in list(range(1, 2000, 7)) + [1, 2, 3, 99, 100, 199, 200, 1999]:
+                try:
+                    want = n ** (1. / t)
+                except OverflowError:
+                    continue
+                worst = max(worst, abs(L.orc_det_pow(float(n), 1. / t) - want) / want)
+    assert worst < 1e-13, worst
+    assert L.orc_det_pow(0.0, 4.0) == 0.0 and L.orc_det_pow(1.0, 1. / 0.75) == 1.0
 
 
 def test_tree_invariants_random_mode():

@@ -10,6 +10,8 @@ the two-line shim of SURVEY.md Appendix B and records small fixtures under tests
                          fair_max, with and without closed-form Dirichlet noise (exact N, Q 1e-12)
   G4 selfplay_<game>.npz AlphaZeroTrainer.self_play memory (samples before/after normalise and
                          after the symmetry augmentation) under the same patches
+     selfplay_frac_<game>.npz  the same with temp_max_step = 2, temp_min_step = 6: plies 3-5 at tau = 0.75 / 0.5 / 0.25, where
+                         get_action_probs is N ** (1 / tau) / sum (mcts.py:114-116)
   G5 stats.npz           outcome statistics of reference rollout-MCTS TicTacToe self-play
   G7 arena_<game>.npz    Arena.play_games (arena.py:119-185) between AlphaZeroPlayer (closed-form fake net, no noise) and GreedyPlayer /
                          another AlphaZeroPlayer under the deterministic fair_max: every move of every round, who started, winners,
@@ -328,13 +330,18 @@ def gen_mct(R, tag, positions, n_pos=32):
 
 
 # ------------------------------------------------------------------------------------------- G4
-def gen_selfplay(R, tag, episodes, sims, seed=7):
+def gen_selfplay(R, tag, episodes, sims, seed=7, temp_steps=None, name="selfplay"):
+    """temp_steps = (temp_max_step, temp_min_step) overrides the game's config (equal steps there: tau is 1, then 0); with
+    temp_max_step < temp_min_step - 1 the linear schedule (schedulers.py:33-40) passes through fractional temperatures, where
+    get_action_probs computes N ** (1 / tau) (mcts.py:114-116) -- the base defaults 15 / 20 (base.py:70-72) do"""
     game, kw, A, n = GAMES[tag]
     T = R.trainer
     cfg_cls = R.registers.CONFIGS_REGISTER[game]
     extra = {}
     if game == "othello":
         extra["board_size"] = n
+    if temp_steps is not None:
+        extra["temp_max_step"], extra["temp_min_step"] = temp_steps
     cfg = cfg_cls(simulations=sims, episodes=episodes, data_augmentation=True, **extra)
     tr = T.AlphaZeroTrainer(verbose=False)
     tr.config, tr.game = cfg, game
@@ -365,7 +372,7 @@ def gen_selfplay(R, tag, episodes, sims, seed=7):
     mem = tr.memory
     transf = sorted(set(str(s.transformation) for s in mem))
     np.savez_compressed(
-        os.path.join(GOLD, f"selfplay_{tag}.npz"),
+        os.path.join(GOLD, f"{name}_{tag}.npz"),
         state=np.array([s.state for s in mem]).astype(np.int8), pi=np.array([s.pi for s in mem], np.float64),
         outcome=np.array([s.outcome for s in mem], np.int8), player=np.array([s.player for s in mem], np.int8),
         episode_idx=np.array([s.episode_idx for s in mem], np.int32), move_idx=np.array([s.move_idx for s in mem], np.int32),
@@ -373,7 +380,7 @@ def gen_selfplay(R, tag, episodes, sims, seed=7):
         sims=np.int32(sims), episodes=np.int32(episodes), seed=np.int32(seed), alpha=cfg.dirichlet_alpha, eps=cfg.dirichlet_epsilon,
         temp_max_step=np.int32(cfg.temp_max_step), temp_min_step=np.int32(cfg.temp_min_step))
     n_orig = sum(1 for s in mem if s.transformation is None)
-    print(f"selfplay_{tag}: {n_orig} samples (+{len(mem) - n_orig} augmented), transformations={transf}")
+    print(f"{name}_{tag}: {n_orig} samples (+{len(mem) - n_orig} augmented), transformations={transf}")
 
 
 # ------------------------------------------------------------------------------------------- G7
@@ -510,6 +517,7 @@ def main():
             gen_net(R, tag, positions)
             gen_mct(R, tag, positions)
             gen_selfplay(R, tag, *sp[tag])
+            gen_selfplay(R, tag, *sp[tag], seed=11, temp_steps=(2, 6), name="selfplay_frac")  # tau = 1, 1, 1, .75, .5, .25, 0 ...
     if not want or "stats" in want:
         gen_stats(R)
     for tag in SGD_PLAN:
