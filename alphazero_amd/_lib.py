@@ -41,7 +41,7 @@ SYMBOLS = [
     "az_engine_root_children", "az_engine_nodes_used", "az_engine_grow_pools", "az_engine_play", "az_augment_count", "az_augment",
     "az_engine_set_sides", "az_engine_best_moves", "az_engine_baseline_moves", "az_engine_root_status",
     "az_trainer_create", "az_trainer_destroy", "az_trainer_load", "az_trainer_store", "az_trainer_begin", "az_trainer_set_lr",
-    "az_trainer_steps", "az_trainer_debug",
+    "az_trainer_steps", "az_trainer_check", "az_trainer_debug",
 ]
 
 
@@ -105,7 +105,8 @@ def lib():
     L.az_trainer_store.argtypes = [vp, C.c_char_p, vp, i64, vp]
     L.az_trainer_begin.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, vp]
     L.az_trainer_set_lr.argtypes = [vp, C.c_float, vp]
-    L.az_trainer_steps.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.az_trainer_steps.argtypes = [vp, vp, vp, vp, i64, vp, i32, i32, vp, vp, vp]
+    L.az_trainer_check.argtypes = [vp]
     L.az_trainer_debug.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)]
     _LIB = L
     return L

@@ -104,12 +104,10 @@ class BatchedArena:
         import numpy as np
         import torch
         from collections import defaultdict
-        from .dist import all_gather_rows, initialized, rank_world
+        from .dist import gather_sharded_rows, initialized, rank_world, shard_range
         _check_rounds(n_rounds, start_player)
         rank, world = rank_world() if shard else (0, 1)
-        per = (n_rounds + world - 1) // world
-        lo = min(n_rounds, rank * per)
-        G = min(per, n_rounds - lo)
+        lo, G, per = shard_range(n_rounds, rank, world)
         p2_all = np.array([{1: False, 2: True}.get(start_player, bool(r % 2)) for r in range(n_rounds)])
         side_all = np.where(p2_all, -1, 1).astype(np.int8)  # colour +1 moves first
         res = np.full((per, 2), -2, np.int32)  # (winner, score) of this rank's rounds, padded to `per` rows
@@ -119,8 +117,7 @@ class BatchedArena:
             res[:G, 0], res[:G, 1] = winner, score
         if shard and initialized():  # also with one rank: the collective is part of the path
             dev = "cuda" if torch.distributed.get_backend() != "gloo" else "cpu"
-            res_all = all_gather_rows(torch.from_numpy(res).to(dev), force=True).cpu().numpy().reshape(world, per, 2)
-            res = np.concatenate([res_all[r, :min(per, max(0, n_rounds - r * per))] for r in range(world)])
+            res = gather_sharded_rows(torch.from_numpy(res).to(dev), n_rounds, force=True).cpu().numpy()
         winner, score = res[:n_rounds, 0], res[:n_rounds, 1]
         stats = {"player1": [], "player2": [], "draw": 0, "player1_starts": defaultdict(int), "player2_starts": defaultdict(int)}
         for g in range(n_rounds):

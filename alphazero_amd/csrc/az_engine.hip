@@ -1097,6 +1097,11 @@ static int dev_alloc(az_engine *e, T **p, size_t n) {
 static inline dim3 grid_for(int n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 #define TB 64
 
+// between az_engine_search_begin and _end the search's launches are in flight and its error flags unread: every other entry point of
+// the engine (they reorder host-side state -- sim_base, active_bound, the graph cache -- or read device state the search is writing)
+// refuses until the search has been ended
+#define AZ_NO_OPEN_SEARCH(e, who) AZ_REQUIRE(!(e)->search_open, AZ_ESTATE, who ": a search begun with az_engine_search_begin has not been ended (az_engine_search_end)")
+
 extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *stream, az_engine **out) {
     AZ_REQUIRE(cfg && out, AZ_EINVAL, "null argument");
     GameDesc gd;
@@ -1149,9 +1154,17 @@ extern "C" int az_engine_create(const az_engine_cfg *cfg, az_net *net, void *str
     return AZ_OK;
 }
 
+static int fetch_counters(az_engine *e);
+static int check_err(az_engine *e);
+
 extern "C" void az_engine_destroy(az_engine *e) {
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->search_open) {  // destroyed with a search still open: its errors would vanish with the engine -- say so
+        e->search_open = false;
+        if (fetch_counters(e) == AZ_OK && check_err(e) != AZ_OK)
+            fprintf(stderr, "az_engine_destroy: the search that was never ended had failed: %s\n", az_last_error());
+    }
     for (auto &kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -1264,6 +1277,7 @@ static int check_err(az_engine *e) {
 
 extern "C" int az_engine_run(az_engine *e, uint32_t first_game_id, int32_t n_games) {
     AZ_REQUIRE(e && n_games > 0, AZ_EINVAL, "bad arguments");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_run");
     AZ_TRY(enter(e));
     EngDev &d = e->d;
     e->lockstep_iters = 0;
@@ -1308,6 +1322,7 @@ extern "C" int az_engine_get_stats(az_engine *e, az_engine_stats *out) {
 extern "C" int az_engine_samples(az_engine *e, int64_t *n_samples, const int8_t **d_states, const float **d_pis,
                                  const int8_t **d_zs, const int32_t **d_meta, const int32_t **d_visits) {
     AZ_REQUIRE(e && n_samples, AZ_EINVAL, "null argument");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_samples");
     AZ_TRY(fetch_counters(e));
     long long s = (long long)e->h_ctr[CTR_SAMPLES];
     *n_samples = s < e->cfg.sample_capacity ? s : e->cfg.sample_capacity;
@@ -1321,8 +1336,9 @@ extern "C" int az_engine_samples(az_engine *e, int64_t *n_samples, const int8_t 
 
 extern "C" int az_engine_set_roots(az_engine *e, const int8_t *h_grids, const int8_t *h_players, const uint32_t *h_game_ids,
                                    const int32_t *h_plies, int32_t n_roots) {
-    if (e) e->sim_base = 0;
     AZ_REQUIRE(e && h_grids && h_players, AZ_EINVAL, "null argument");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_set_roots");
+    e->sim_base = 0;
     EngDev &d = e->d;
     AZ_REQUIRE(n_roots > 0 && n_roots <= d.G, AZ_EINVAL, "n_roots must be in [1, n_slots]");
     AZ_TRY(enter(e));
@@ -1356,6 +1372,7 @@ extern "C" int az_engine_set_roots(az_engine *e, const int8_t *h_grids, const in
 
 extern "C" int az_engine_search(az_engine *e, int32_t n_sim) {
     AZ_REQUIRE(e && n_sim > 0, AZ_EINVAL, "bad arguments");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_search");
     AZ_TRY(enter(e));
     AZ_TRY(do_search(e, n_sim));
     AZ_TRY(fetch_counters(e));
@@ -1403,8 +1420,9 @@ extern "C" int az_engine_pair(az_engine *a, az_engine *b) {
 }
 
 extern "C" int az_engine_advance(az_engine *e) {
-    if (e) e->sim_base = 0;
     AZ_REQUIRE(e, AZ_EINVAL, "null argument");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_advance");
+    e->sim_base = 0;
     EngDev &d = e->d;
     // games that end here must not be refilled: cap the queue at what has been started
     hipLaunchKernelGGL(k_move, grid_for(d.G, TB), dim3(TB), 0, e->stream, d);
@@ -1416,6 +1434,7 @@ extern "C" int az_engine_advance(az_engine *e) {
 extern "C" int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_actions, int32_t *h_N, double *h_Q,
                                        double *h_P, int32_t *count, int32_t *root_N) {
     AZ_REQUIRE(e && count, AZ_EINVAL, "null argument");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_root_children");
     EngDev &d = e->d;
     AZ_REQUIRE(slot >= 0 && slot < d.G, AZ_EINVAL, "slot out of range");
     AZ_HIP(hipStreamSynchronize(e->stream));
@@ -1445,6 +1464,7 @@ extern "C" int az_engine_root_children(az_engine *e, int32_t slot, int32_t *h_ac
 // and again without a move, mcts.py:226-269) checks before the next search.
 extern "C" int az_engine_nodes_used(az_engine *e, int32_t slot, int32_t *n_nodes) {
     AZ_REQUIRE(e && n_nodes, AZ_EINVAL, "null argument");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_nodes_used");
     AZ_REQUIRE(slot >= 0 && slot < e->d.G, AZ_EINVAL, "slot out of range");
     AZ_HIP(hipStreamSynchronize(e->stream));
     AZ_HIP(hipMemcpy(n_nodes, e->d.n_nodes + slot, sizeof(int), hipMemcpyDeviceToHost));
@@ -1455,6 +1475,7 @@ extern "C" int az_engine_nodes_used(az_engine *e, int32_t slot, int32_t *n_nodes
 // The reference's tree grows without bound; here the pools are sized per search and grown on demand by the single-game MCT.
 extern "C" int az_engine_grow_pools(az_engine *e, int32_t node_capacity) {
     AZ_REQUIRE(e, AZ_EINVAL, "null argument");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_grow_pools");
     EngDev &d = e->d;
     AZ_REQUIRE(node_capacity >= d.C, AZ_EINVAL, "pools can only grow (%d < %d)", node_capacity, d.C);
     if (node_capacity == d.C) return AZ_OK;
@@ -1481,8 +1502,9 @@ extern "C" int az_engine_grow_pools(az_engine *e, int32_t node_capacity) {
 }
 
 extern "C" int az_engine_play(az_engine *e, const int32_t *h_actions, int32_t n, int32_t *h_status) {
-    if (e) e->sim_base = 0;
     AZ_REQUIRE(e && h_actions && h_status, AZ_EINVAL, "null argument");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_play");
+    e->sim_base = 0;
     EngDev &d = e->d;
     AZ_REQUIRE(n > 0 && n <= d.G, AZ_EINVAL, "n must be in [1, n_slots]");
     int *d_act = e->scr_a, *d_st = e->scr_b;
@@ -1507,6 +1529,7 @@ extern "C" int az_debug_read_step_probe(unsigned long long *h_out, int n_words) 
 // ---- arena support ---------------------------------------------------------------
 extern "C" int az_engine_set_sides(az_engine *e, const int8_t *h_sides, int32_t n) {
     AZ_REQUIRE(e && h_sides && n > 0 && n <= e->d.G, AZ_EINVAL, "bad arguments");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_set_sides");
     AZ_HIP(hipMemcpyAsync(e->d.side, h_sides, (size_t)n, hipMemcpyHostToDevice, e->stream));
     AZ_HIP(hipStreamSynchronize(e->stream));
     return AZ_OK;
@@ -1524,16 +1547,19 @@ static int moves_out(az_engine *e, int32_t *h_actions, int which, int kind, uint
 
 extern "C" int az_engine_best_moves(az_engine *e, int32_t *h_actions) {
     AZ_REQUIRE(e && h_actions, AZ_EINVAL, "null argument");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_best_moves");
     return moves_out(e, h_actions, 0, 0, 0);
 }
 
 extern "C" int az_engine_baseline_moves(az_engine *e, int32_t kind, uint32_t seed, int32_t *h_actions) {
     AZ_REQUIRE(e && h_actions && (kind == 0 || kind == 1), AZ_EINVAL, "bad arguments (kind: 0 random, 1 greedy)");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_baseline_moves");
     return moves_out(e, h_actions, 1, kind, seed);
 }
 
 extern "C" int az_engine_root_status(az_engine *e, int8_t *h_players, uint8_t *h_over, int8_t *h_winner, int32_t *h_score) {
     AZ_REQUIRE(e && h_players && h_over && h_winner && h_score, AZ_EINVAL, "null argument");
+    AZ_NO_OPEN_SEARCH(e, "az_engine_root_status");
     EngDev &d = e->d;
     char *buf = e->scr_c;
     size_t G = d.G;

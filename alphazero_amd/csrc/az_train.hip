@@ -68,7 +68,18 @@ struct Hyper {        // device-resident so that a captured step never goes stal
     int step;         // steps done since az_trainer_begin (k_update increments it)
     int perm_off;     // permutation entries consumed so far: row of board b = perm[perm_off + b]
     int loss_off;     // slot of this step's losses in loss_pi / loss_v
+    long long n_samples;  // rows of the caller's sample arrays: a permutation entry outside [0, n_samples) is an error, not an address
+    int err;          // sticky: set by sample_row, reported (and cleared) by az_trainer_check / the next az_trainer_steps
+    int pad_;
 };
+
+// row of the sample arrays that batch slot i trains on (trainer.py:288-318 draws the indices from len(memory)); an entry outside the
+// arrays raises the error flag and reads row 0 instead of faulting the GPU
+AZ_D long long sample_row(const long long *perm, int i, const Hyper &hp, Hyper *dev) {
+    long long r = perm[i];
+    if (r < 0 || r >= hp.n_samples) { atomicOr(&dev->err, 1); r = 0; }
+    return r;
+}
 
 struct PSet {         // one set of tensors in the step's own layout (parameters; the momentum buffers mirror it)
     float *cw[4];     // conv1 [9][32 oc]; conv2..4 [9 taps][32 ic][32 oc]
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(TPB) void k_conv1_fwd(TDims d, TPtr q) {
     double n = 0.0, mean = 0.0, M2 = 0.0;
     __syncthreads();
     for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
-        const long long row = q.perm[hp.perm_off + b];
+        const long long row = sample_row(q.perm, hp.perm_off + b, hp, q.hp);
         for (int p = t; p < d.P1; p += TPB) {
             const float v = (float)q.state[row * d.P1 + p];
             xin[(p / d.CW + 1) * WP + p % d.CW + 1] = v;
@@ -670,7 +681,7 @@ __global__ __launch_bounds__(NW * 64) void k_heads_fwd(TDims d, TPtr q) {
     const int chunk = ((K / 16 + NW - 1) / NW) * 16, kbeg = wave * chunk, kend = min(K, kbeg + chunk);
     // the targets of row t >> 4 (perm -> pi, z: two dependent trips) travel under the K loop
     const int row = (t >> 4) & 15, j = t & 15;
-    const long long brow = q.perm[hp.perm_off + r0 + row];
+    const long long brow = sample_row(q.perm, hp.perm_off + r0 + row, hp, q.hp);
     float pit[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) pit[i] = j + 16 * i < A ? q.pi[brow * A + j + 16 * i] : 0.f;
@@ -1432,7 +1443,7 @@ __global__ __launch_bounds__(TPB) void k_ttt_step(TttPtr q, int B) {
     const Hyper hp = *q.hp;
     for (int i = t; i < TT_N; i += TPB) w[i] = q.p[i];
     for (int r = t; r < B; r += TPB) {
-        const long long row = q.perm[hp.perm_off + r];
+        const long long row = sample_row(q.perm, hp.perm_off + r, hp, q.hp);
 #pragma unroll
         for (int k = 0; k < 9; ++k) x[r * TT_LD + k] = (float)q.state[row * 9 + k];
     }
@@ -1464,7 +1475,7 @@ __global__ __launch_bounds__(TPB) void k_ttt_step(TttPtr q, int B) {
     double lpi = 0.0, lv = 0.0;
     const float invB = 1.0f / (float)B;
     for (int r = t; r < B; r += TPB) {  // bn2 + relu, heads, loss, d loss / d logits
-        const long long row = q.perm[hp.perm_off + r];
+        const long long row = sample_row(q.perm, hp.perm_off + r, hp, q.hp);
         float a[9], lg[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) { a[k] = fmaxf(fmaf(w[TT_G2 + k], (y2[r * TT_LD + k] - s_mu2[k]) * s_iv2[k], w[TT_BE2 + k]), 0.f); a2[r * TT_LD + k] = a[k]; }
@@ -1865,9 +1876,28 @@ static int enqueue_step(az_trainer *t) {  // (row tiles, waves that split K, pre
 
 // n_steps optimisation steps on device-resident samples: step s trains on rows d_perm[s * B .. s * B + B) of (d_state int8 [S][cells],
 // d_pi f32 [S][A], d_z int8 [S]) and writes its policy / value loss to d_loss_pi[s] / d_loss_v[s].  Asynchronous on `stream`.
-extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const float *d_pi, const int8_t *d_z, const int64_t *d_perm, int32_t n_steps,
-                                int32_t B, float *d_loss_pi, float *d_loss_v, void *stream) {
+static int check_rows(az_trainer *t) {  // the stream is idle: read and clear the sticky flag of sample_row
+    int err = 0;
+    AZ_HIP(hipMemcpy(&err, &t->q.hp->err, sizeof err, hipMemcpyDeviceToHost));
+    if (err) {
+        const int zero = 0;
+        AZ_HIP(hipMemcpy(&t->q.hp->err, &zero, sizeof zero, hipMemcpyHostToDevice));
+        AZ_REQUIRE(false, AZ_EINVAL, "a permutation entry of the last az_trainer_steps call was outside [0, n_samples): those batch slots trained on row 0");
+    }
+    return AZ_OK;
+}
+
+// waits for the steps enqueued so far and reports a permutation entry that was out of range (the kernels clamp it and raise a flag)
+extern "C" int az_trainer_check(az_trainer *t) {
+    AZ_REQUIRE(t, AZ_EINVAL, "null trainer");
+    AZ_HIP(hipStreamSynchronize(t->stream));
+    return check_rows(t);
+}
+
+extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const float *d_pi, const int8_t *d_z, int64_t n_samples, const int64_t *d_perm,
+                                int32_t n_steps, int32_t B, float *d_loss_pi, float *d_loss_v, void *stream) {
     AZ_REQUIRE(t && d_state && d_pi && d_z && d_perm && d_loss_pi && d_loss_v, AZ_EINVAL, "null argument");
+    AZ_REQUIRE(n_samples > 0, AZ_EINVAL, "n_samples = %lld: the sample arrays are empty", (long long)n_samples);
     if (t->game == AZ_TICTACTOE) AZ_REQUIRE(B >= 2 && B <= t->max_batch, AZ_EINVAL, "batch size %d outside [2, %d]", B, t->max_batch);
     else AZ_REQUIRE(B >= 16 && B <= t->max_batch && B % 16 == 0, AZ_EINVAL, "batch size %d: need a multiple of 16 in [16, %d]", B, t->max_batch);
     AZ_REQUIRE(n_steps >= 0, AZ_EINVAL, "negative step count");
@@ -1887,9 +1917,12 @@ extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const floa
     t->q.state = d_state; t->q.pi = d_pi; t->q.z = d_z; t->q.perm = (const long long *)d_perm; t->q.loss_pi = d_loss_pi; t->q.loss_v = d_loss_v;
     t->tq.state = d_state; t->tq.pi = d_pi; t->tq.z = d_z; t->tq.perm = (const long long *)d_perm; t->tq.loss_pi = d_loss_pi; t->tq.loss_v = d_loss_v;
     t->g_state = d_state; t->g_pi = d_pi; t->g_z = d_z; t->g_perm = d_perm; t->g_lp = d_loss_pi; t->g_lv = d_loss_v; t->g_B = B;
-    const int zero2[2] = {0, 0};  // perm_off, loss_off: this call's arrays start at 0 (the step counter keeps running: dropout streams)
-    AZ_HIP(hipMemcpyAsync(&t->q.hp->perm_off, zero2, sizeof zero2, hipMemcpyHostToDevice, t->stream));
     AZ_HIP(hipStreamSynchronize(t->stream));
+    AZ_TRY(check_rows(t));  // of an earlier call nobody checked
+    // perm_off, loss_off: this call's arrays start at 0 (the step counter keeps running: dropout streams); n_samples bounds its rows
+    struct { int perm_off, loss_off; long long n_samples; int err, pad_; } tail = {0, 0, (long long)n_samples, 0, 0};
+    static_assert(sizeof tail == sizeof(Hyper) - offsetof(Hyper, perm_off), "Hyper tail layout");
+    AZ_HIP(hipMemcpy(&t->q.hp->perm_off, &tail, sizeof tail, hipMemcpyHostToDevice));
     int done = 0;
     if (t->steps_done == 0) {  // the very first step of a trainer runs as plain launches: kernel attributes get set outside a capture
         AZ_TRY(enqueue_step(t));

@@ -28,6 +28,26 @@ def rank_game_range(rank, world_size, games_per_rank, wave=0):
     return first, games_per_rank
 
 
+def shard_range(n, rank, world):
+    """(first, count, per): the contiguous block of n units (episodes of an iteration, rounds of an arena) that `rank` works on;
+    `per` = ceil(n / world) is every rank's padded block length.  The last ranks of a job with more ranks than units get count 0."""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(per, n - lo), per
+
+
+def gather_sharded_rows(local, n, group=None, force=False):
+    """`local`: this rank's [per, ...] block of per-unit results (the first `count` rows of shard_range are real, the rest padding).
+    -> the [n, ...] results of all units in unit order, on every rank.  One fixed-size all-gather (a few bytes per unit)."""
+    if not initialized() or (dist.get_world_size(group) == 1 and not force):
+        return local[:n]
+    world = dist.get_world_size(group)
+    per = local.shape[0]
+    assert per == (n + world - 1) // world, (per, n, world)
+    rows = all_gather_rows(local, group=group, force=True).view((world, per) + tuple(local.shape[1:]))
+    return torch.cat([rows[r, :shard_range(n, r, world)[1]] for r in range(world)])
+
+
 def _pack_layout(samples, n_rows):
     """byte offsets of every field in the packed per-rank buffer (fields in sorted key order, n_rows rows each)"""
     off, layout = 0, {}

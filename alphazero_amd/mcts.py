@@ -155,6 +155,7 @@ class MCT:
             self._engine.set_roots(board.grid.astype(np.int8)[None], np.array([board.player], np.int8),
                                    game_ids=np.array([np.random.randint(0, 2**31 - 1)], np.uint32))
             self._root_key = key
+            self._used_bound = 1  # a fresh tree: the root
         self._last_board = board.clone()
 
     _MAX_POOL = 1 << 24  # nodes per pool (512 MiB): beyond it the engine reports AZ_ECAPACITY
@@ -162,9 +163,20 @@ class MCT:
     def _ensure_room(self, n_sim):
         """the reference's tree grows without bound while search() is called again and again on one root (mcts.py:226-269);
         the device pools have a size: before a search of n_sim simulations (each allocates at most one node's children, <= A <= 65
-        nodes) the pools are re-allocated when what is left could run out.  The tree is kept (az_engine_grow_pools)."""
+        nodes) the pools are re-allocated when what is left could run out.  The tree is kept (az_engine_grow_pools).
+
+        The device is only asked for the node count (a stream synchronisation + a blocking copy) when a HOST-side upper bound --
+        the last count read plus 66 nodes per simulation since -- nears the capacity: a compute_time search of one simulation per
+        chunk would otherwise pay that round trip per simulation.  A tree that cannot fit the largest pool is refused up front."""
         eng = self._engine
-        need = eng.nodes_used(0) + 66 * n_sim + 66
         cap = eng.cfg.node_capacity
+        self._used_bound = getattr(self, "_used_bound", cap) + 66 * n_sim
+        if self._used_bound + 66 <= cap:
+            return
+        need = eng.nodes_used(0) + 66 * n_sim + 66
+        self._used_bound = need - 66
         if need > cap:
-            eng.grow_pools(min(self._MAX_POOL, max(2 * cap, need)))
+            if need > self._MAX_POOL:
+                raise MemoryError(f"MCT.search: the tree would need {need} nodes, beyond the device pool limit of {self._MAX_POOL} "
+                                  f"(the search has run {need // 66} simulations' worth of expansions on one root without a move)")
+            eng.grow_pools(min(self._MAX_POOL, max(2 * cap, need + 66 * 1024)))  # one growth covers many chunks

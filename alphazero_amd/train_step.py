@@ -23,12 +23,20 @@ def supports(module, batch_size):
         return False
     gid, H, W = module.hip_shape()
     if gid == 2:
-        return 2 <= batch_size <= 256
+        # TicTacToeNet (tictactoe.py:272-287): 9 -> 9 -> 9 -> (9, 1), 316 parameters
+        return 2 <= batch_size <= 256 and sum(p.numel() for p in module.parameters()) == 316
     if not hasattr(module, "conv1"):
         return False
     if gid == 0 and H not in (6, 8):
         return False
     if gid == 1 and not (5 <= H <= 8 and 5 <= W <= 8):
+        return False
+    # az_trainer_create builds the reference's architecture: 32 channels, fc widths 1024 / 512 (OthelloNet, othello.py:329-333) or
+    # 64 / 32 (Connect4Net, connect4.py:357-361) behind 32 * (h - 4) * (w - 4) inputs; any other module trains on the stock step
+    ch, cw = getattr(module, "plane", (H, W))
+    want = (32, 32 * (ch - 4) * (cw - 4)) + ((1024, 512) if gid == 0 else (64, 32))
+    have = (module.conv1.out_channels, module.fc1.in_features, module.fc1.out_features, module.fc2.out_features)
+    if have != want or any(getattr(module, f"conv{i}").out_channels != 32 for i in (2, 3, 4)):
         return False
     return batch_size % 16 == 0 and 16 <= batch_size <= 512
 
@@ -86,12 +94,14 @@ class HipTrainStep:
         S = state.shape[0]
         if pi.shape[0] != S or z.shape[0] != S:
             raise ValueError(f"sample arrays disagree on the number of rows: state {S}, pi {pi.shape[0]}, z {z.shape[0]}")
-        used = perm[: n_steps * batch_size]
-        if used.numel() and (int(used.min()) < 0 or int(used.max()) >= S):  # once per epoch: the kernels index the samples unchecked
-            raise ValueError(f"permutation entries outside [0, {S})")
-        check(lib().az_trainer_steps(self.h, state.data_ptr(), pi.data_ptr(), z.data_ptr(), perm.data_ptr(), n_steps, batch_size,
+        # the row count crosses the ABI: a permutation entry outside [0, S) is clamped by the kernels and reported by check()
+        check(lib().az_trainer_steps(self.h, state.data_ptr(), pi.data_ptr(), z.data_ptr(), S, perm.data_ptr(), n_steps, batch_size,
                                      loss_pi.data_ptr(), loss_v.data_ptr(), _stream()))
         self.steps_done += n_steps
+
+    def check(self):
+        """waits for the enqueued steps; ValueError if one of their permutation entries lay outside the sample arrays"""
+        check(lib().az_trainer_check(self.h))
 
     def debug(self, name, shape=None):
         """a workspace buffer of the last step as a CUDA tensor copy (tests)"""

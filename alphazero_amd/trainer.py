@@ -147,10 +147,8 @@ class AlphaZeroTrainer:
         else:
             # the episodes are sharded by game id (disjoint Philox streams, no collective while playing), then every
             # rank receives all samples: the same memory a single process would have built
-            from .dist import all_gather_samples
-            per = (n + world - 1) // world
-            lo = min(n, rank * per)
-            cnt = min(per, n - lo)
+            from .dist import all_gather_samples, shard_range
+            lo, cnt, _ = shard_range(n, rank, world)
             if cnt > 0:
                 smp = eng.run(cnt, first_game_id=iter_idx * n + lo)
             else:
@@ -246,6 +244,7 @@ class AlphaZeroTrainer:
             lv = torch.empty(n_batches, dtype=torch.float32, device="cuda")
             ts.set_lr(lr)
             ts.steps(state, pi, z, perm, n_batches, bs, lp, lv)
+            ts.check()  # the epoch is done; a permutation entry outside the memory is a ValueError
             self.loss_values[iter_idx][epoch] = {"pi": lp.cpu().tolist(), "v": lv.cpu().tolist()}
             lr = lr * 0.9  # torch.optim.lr_scheduler.ExponentialLR(gamma=0.9) (trainer.py:327)
         ts.store(self.nn_twin)

@@ -1,24 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: self-play games/s, Othello 8x8 @ 100 sims/move (BASELINE.json configs[1]).
+"""Headline benchmark: self-play games/s, Othello 8x8 @ 100 sims/move, 4096 concurrent games per GPU (BASELINE.json configs[1];
+at N GPUs: configs[2] = the same per GPU, sharded, + the RCCL all-gather of the samples).
 
   python bench.py --gpus N --steps K --warmup W
 Started plainly with N > 1 it launches its own N ranks (one child process per GPU, spawned BEFORE the parent makes any HIP call; the
 parent only relays rank 0's JSON line and fails if any rank fails); under torch.distributed.run (WORLD_SIZE set) it is one rank.
 
-A "step" is one self-play wave: every rank keeps `--games` Othello 8x8 games resident and plays them from the start
-position to the end at 100 MCTS simulations per move through the HIP engine (random-init OthelloNet(n=8) under
-torch.manual_seed(0), Dirichlet noise 0.03/0.25, tau linear(4,4), tree reuse) and, for N > 1, all-gathers the samples over
-RCCL.  value = games of all ranks / time.  The timed region runs the engine as it ships (searches replayed as HIP
-graphs, no event recording); the per-kernel times of the roofline come from one extra, separately profiled step.
+A "step" is one self-play wave at BASELINE's LITERAL size: every rank keeps `--games` (4096) Othello 8x8 games resident and plays them
+from the start position to the end at 100 MCTS simulations per move through the HIP engine (random-init OthelloNet(n=8) under
+torch.manual_seed(0), Dirichlet noise 0.03/0.25, tau linear(4,4), tree reuse) and, for N > 1, all-gathers the samples over RCCL.
+value = games of all ranks / time; K steps = K waves (">= 2 waves, steady-state rate").  The timed region runs the engine as
+it ships (searches replayed as HIP graphs, no event recording); the per-kernel times of the roofline come from one extra, separately
+profiled step.
 
-At N = 1 the same JSON line also carries the two single-GPU BASELINE configs at their LITERAL sizes:
-  config2 : Othello 8x8, 4096 concurrent games, 100 sims/move           (BASELINE.json configs[1])
-  config4 : Connect4 6x7, 8192 concurrent games, 200 sims/move          (BASELINE.json configs[3])
-each with games/s, examples/s and its own roofline object, `config5` (BASELINE.json configs[4]: the trainer loop on Othello 8x8,
-per-phase seconds) and `cpu_baseline`: the CPU oracle (C port of the reference's self-play loop) timed on the host cores with the
-protocol of BASELINE.md section 3, and `latency`: the shapes the reference itself is used in (one game's search, self-play waves of 64
-and 512 games, an evaluation arena of 64 games), where a lock-step is five dependent launches on an almost empty chip.  At N > 1 the line carries `config3` (BASELINE.json configs[2] at its LITERAL size: 32768
-concurrent games sharded N ways, RCCL sample all-gather) and `config5` over all ranks.
+The driver's record keeps the scalar fields of `config`, `roofline` and `cpu_baseline` (nested objects and long strings are cut), so
+everything that has to survive there is a FLAT scalar inside `config` / `roofline`:
+  config.saturated_*   the same workload at 32768 concurrent games per GPU (where the rate has flattened: the chip is full)
+  config.config4_*     BASELINE.json configs[3]: Connect4 6x7, 8192 concurrent games, 200 sims/move, at its literal size
+  config.config1_*     BASELINE.json configs[0]: 2 TicTacToe rollout-MCTS games (device MCTSPlayer; the oracle's time is in cpu_baseline)
+  config.config3_*     N > 1 and 32768 / N != 4096: configs[2] at its literal TOTAL (32768 games sharded N ways)
+The full objects (`saturated`, `config4`, `config1`, `config3`, `config5`, `latency`, `tree_hbm`) follow as top-level extras.
 
 How to read `roofline` (every field can be recomputed from profiles/ + the fields beside it):
   kernel            the kernel with the largest share of the profiled step's network time; fc1 and fc2 are ONE kernel (two launches
@@ -106,30 +107,57 @@ def stamped(name):
 def self_launch(n):
     """`python bench.py --gpus N` started plainly: N fresh child processes, one per GPU, each with the environment
     torch.distributed.run would give it.  The parent has made no HIP call (torch is not even imported) and makes none: it waits,
-    relays rank 0's stdout (the JSON line) and exits non-zero as soon as any rank fails (the others are then terminated)."""
+    relays rank 0's stdout (the JSON line) and exits non-zero as soon as any rank fails.  Whatever ends the parent -- a failing rank,
+    SIGTERM / SIGINT from a harness time limit, an exception -- the ranks it started are terminated and, after a grace period, killed
+    (exactly those PIDs): a rank blocked in a collective must not outlive the run holding its GPU."""
+    import signal
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AZ_BENCH_SELF_LAUNCHED="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))  # rank 0 inherits stdout: its JSON line is ours
+
+    def stop_all(grace=float(os.environ.get("AZ_BENCH_KILL_GRACE_S", "10"))):
+        live = [q for q in procs if q.poll() is None]
+        for q in live:
+            q.terminate()
+        t_end = time.time() + grace
+        for q in live:
+            try:
+                q.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
+
+    def on_signal(signum, _frame):
+        raise KeyboardInterrupt(f"signal {signum}")
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    alive = set(range(n))
-    while alive:
-        for r in sorted(alive):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            alive.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
-                for q in alive:
-                    procs[q].terminate()  # exactly the processes started above
-        time.sleep(0.2)
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AZ_BENCH_SELF_LAUNCHED="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else sys.stderr))  # rank 0 inherits stdout: its JSON line is ours
+        alive = set(range(n))
+        while alive and rc == 0:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+            if alive and rc == 0:
+                time.sleep(0.2)
+    except KeyboardInterrupt as e:
+        print(f"bench.py: interrupted ({e}); stopping the ranks", file=sys.stderr, flush=True)
+        rc = 130
+    finally:
+        stop_all()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return rc
 
 
@@ -144,6 +172,31 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_share():
+    """how many host cores this process may use, and where the figure comes from: the cgroup CPU quota (v2 cpu.max / v1
+    cfs_quota_us) when one is set, else the scheduler affinity mask; -> (cores, source, affinity count, quota or None)"""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < aff:
+        return max(1, int(quota)), "cgroup cpu quota", aff, quota
+    return aff, "sched_getaffinity", aff, quota
+
+
 def cpu_baseline(state_dict, n_sim=100, games_per_proc=3):
     """BASELINE.md section 3 on this box's host cores, with the CPU oracle (the checker; C port of the reference's loop):
     one process, then one process per core of the lease's CPU share, >= 3 games each, every game timed (SelfPlayTimer idiom,
@@ -155,12 +208,13 @@ def cpu_baseline(state_dict, n_sim=100, games_per_proc=3):
     t_all = time.perf_counter()
     one = W.play(weights, games_per_proc, n_sim, 0)
     s1 = np.array(one["seconds_per_game"])
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        usable = os.cpu_count() or 1
-    # a one-GPU lease of the pool owns 16 cores of the host (its 256 hardware threads are shared by 8 leases)
-    nproc = max(1, min(usable, int(os.environ.get("AZ_BENCH_CPU_PROCS", "16"))))
+    usable, share_src, aff, quota = cpu_share()
+    # the multi-process leg: one process per core this process may use, capped at 16 -- the pool's documented CPU share of a one-GPU
+    # lease (worker pools there are to be sized to 16; its host's 256 hardware threads serve 8 leases) -- unless AZ_BENCH_CPU_PROCS
+    # says otherwise.  Which of the three set the number is in `processes_set_by`
+    cap = int(os.environ.get("AZ_BENCH_CPU_PROCS", "16"))
+    nproc = max(1, min(usable, cap))
+    set_by = share_src if usable <= cap else ("AZ_BENCH_CPU_PROCS" if "AZ_BENCH_CPU_PROCS" in os.environ else "documented share of a one-GPU lease (16)")
     many = None
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "w.npz")
@@ -176,15 +230,27 @@ def cpu_baseline(state_dict, n_sim=100, games_per_proc=3):
             plies = sum(json.loads(o.strip().splitlines()[-1])["plies"] for o in outs)
             many = {"processes": nproc, "games": int(len(per)), "wall_s": wall, "games_per_sec": len(per) / wall, "examples_per_sec": plies / wall,
                     "s_per_game_mean": float(per.mean()), "s_per_game_std": float(per.std()),
-                    "note": "one process per core of this lease's CPU share (16 of the host's hardware threads), not of the whole host"}
+                    "note": f"{nproc} processes: {set_by}; usable cores {usable} ({share_src}), not the whole host"}
     net = O.ConvNet(O.OTHELLO, 8, 8, weights)
     t0 = time.perf_counter()
     moves, winners, _, _ = O.arena_games((O.OTHELLO, 8, 8), ("conv", net), n_sim, "mcts", n_sim, seed=0, n_rounds=2)
     t_arena = time.perf_counter() - t0
+    # BASELINE config 1 on the oracle: 2 TicTacToe self-play games, rollout-mode MCTS at 100 simulations, temp 0 (reference 0.159 / 0.171 s)
+    c1 = []
+    for g in range(2):
+        t0 = time.perf_counter()
+        r = O.selfplay(O.TICTACTOE, 3, 3, 1, 100, alpha=-1, eps=-1, temp_max_step=-1, temp_min_step=0, tie_mode=O.TIE_RANDOM,
+                       noise_mode=O.NOISE_OFF, seed=11, first_game_id=g, eval_method=O.EVAL_ROLLOUT)
+        c1.append({"seconds": time.perf_counter() - t0, "plies": int(len(r["z"]))})
     return {"value": 1.0 / float(s1.mean()), "unit": "games/s", "cores": 1, "kind": "port",
-            "sample": f"{games_per_proc} full Othello 8x8 self-play games at {n_sim} sims/move ({one['plies']} plies, {one['net_evals']} net evals) "
-                      f"on 1 host core, oracle/liboracle.so; then {nproc} processes x {games_per_proc} games; then 2 Arena rounds",
-            "cpu_model": cpu_model(), "host_hardware_threads": os.cpu_count(), "usable_cores": usable,
+            "sample": f"{games_per_proc} Othello 8x8 self-play games @{n_sim} sims on 1 core (oracle/liboracle.so); then {nproc} procs; arena; config 1",
+            "cpu_model": cpu_model(), "host_hardware_threads": os.cpu_count(), "usable_cores": usable, "usable_cores_source": share_src,
+            "affinity_cores": aff, "cgroup_cpu_quota": quota, "multi_process_count": nproc, "multi_process_count_set_by": set_by,
+            "multi_process_games_per_sec": many["games_per_sec"] if many else None,
+            "config1_oracle_seconds_game0": c1[0]["seconds"], "config1_oracle_seconds_game1": c1[1]["seconds"],
+            "config1_reference_seconds": "0.159 / 0.171 (BASELINE.md section 2, build container)",
+            "sample_detail": f"{games_per_proc} full games: {one['plies']} plies, {one['net_evals']} net evals",
+            "config1_oracle": c1,
             "one_process": {"games": games_per_proc, "s_per_game_mean": float(s1.mean()), "s_per_game_std": float(s1.std()),
                             "games_per_sec": 1.0 / float(s1.mean()), "examples_per_sec": one["plies"] / float(s1.sum())},
             f"{nproc}_processes": many,
@@ -198,6 +264,28 @@ def cpu_baseline(state_dict, n_sim=100, games_per_proc=3):
 
 
 # ------------------------------------------------------------------------------------------------ one workload
+# the driver's record of the line keeps the scalar fields of `config` / `roofline` / `cpu_baseline` (nested objects dropped, long
+# strings cut): what has to survive there comes first and is a scalar
+ROOF_FIRST = ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "end_to_end_frac", "forward_frac", "mfma_busy", "avg_launch_ms",
+              "launches", "flops_per_board", "boards_evaluated", "kernel_ms_total", "traffic_algorithmic", "share_of_network_time", "trunk_frac",
+              "dense_frac", "heads_frac", "end_to_end_tflops", "avg_boards_per_launch", "network_share_of_profiled_step"]
+
+
+def ordered(d, first):
+    """d with the keys of `first` in front (then scalars, then strings, then nested objects)"""
+    rest = [k for k in d if k not in first]
+    rank = lambda k: 2 if isinstance(d[k], (dict, list)) else (1 if isinstance(d[k], str) else 0)
+    return {k: d[k] for k in [f for f in first if f in d] + sorted(rest, key=rank)}
+
+
+def compact(r):
+    """the flat summary of a run_single / timed_waves result that goes into `config` of the headline line"""
+    ro = r.get("roofline") or {}
+    return {"games_per_sec": r["value"], "examples_per_sec": r.get("examples_per_sec"), "ms_per_step": r.get("ms_per_step"),
+            "end_to_end_frac": ro.get("end_to_end_frac"), "dominant_kernel": (ro.get("kernel") or "")[:40], "dominant_frac": ro.get("frac"),
+            "forward_frac": ro.get("forward_frac")}
+
+
 class Workload:
     """one BASELINE config on this rank's GPU: engine + network + the bookkeeping of the roofline"""
 
@@ -312,7 +400,9 @@ class Workload:
             roof["end_to_end_tflops"] = timed_evals * sum(fl) / timed_seconds / 1e12
         if fused_tail:
             roof["note"] = "Connect4Net: fc1 + fc2 + heads run as ONE fused launch (k_tail_mfma), booked under 'dense'"
-        return roof
+        for k, v in roof["kernels"].items():  # flat copies: the driver's record keeps scalars only
+            roof[f"{k}_frac"], roof[f"{k}_share_of_network_time"] = v["frac"], v["share_of_network_time"]
+        return ordered(roof, ROOF_FIRST)
 
     def close(self):
         self.eng.close()
@@ -391,7 +481,7 @@ class Job:
         return out.view(self.world, -1).cpu().numpy()
 
 
-def timed_waves(job, w, steps, warmup):
+def timed_waves(job, w, steps, warmup, first_wave=0):
     """`steps` self-play waves of w on every rank + (N > 1) the all-gather of the samples, bracketed by barrier + synchronize on
     both sides.  -> dict with the max-over-ranks time and every rank's own time / gather time"""
     from alphazero_amd.dist import all_gather_samples, rank_game_range
@@ -410,13 +500,13 @@ def timed_waves(job, w, steps, warmup):
         return smp["z"].shape[0], st["net_evals"]
 
     for i in range(warmup):
-        step(i)
+        step(first_wave + i)
     gather_s[0] = 0.0
     job.sync()
     t0 = time.perf_counter()
     samples, evals = 0, 0
     for k in range(steps):
-        s, e = step(warmup + k)
+        s, e = step(first_wave + warmup + k)
         samples += s  # after the all-gather every rank holds all ranks' samples
         evals += e
     t_local = time.perf_counter() - t0  # this rank's own time, before it waits for the others
@@ -445,7 +535,7 @@ def run_config3(job, total_games, sims, steps, warmup):
     return out
 
 
-def run_config5(job, episodes, sims, eval_episodes=64, variants=None):
+def run_config5(job, episodes, sims, eval_episodes=64, variants=None, only=None):
     """BASELINE.json configs[4]: AlphaZeroTrainer's loop on Othello 8x8 (trainer.py:475-572: self-play -> optimize_network ->
     update_network -> evaluate against the PREVIOUS network), two iterations per variant with per-phase wall times.  At N > 1 the
     episodes and the evaluation rounds are sharded over the ranks, rank 0 runs the SGD, the weights are broadcast."""
@@ -453,12 +543,16 @@ def run_config5(job, episodes, sims, eval_episodes=64, variants=None):
     from alphazero_amd.games.othello import OthelloConfig
     from alphazero_amd.trainer import AlphaZeroTrainer
     if variants is None:
-        # the reference's hyper-parameters are batch_size 64, 10 epochs (games/othello.py:34-35); ONE epoch is run here (stated), on a
-        # smaller episode count for the batch-64 variant so that both variants do a comparable number of SGD steps
+        # the reference's hyper-parameters are batch_size 64, 10 epochs (games/othello.py:34-35): the `_10_epochs` variant; the others run
+        # ONE epoch (stated), the batch-64 ones on a smaller episode count so that all variants do a comparable number of SGD steps
         variants = [("reference_batch_64", dict(episodes=max(64, episodes // 8), batch_size=64, epochs=1), "hip"),
+                    # the reference's own hyper-parameters (games/othello.py:34-35: 10 epochs of batch 64): what the SGD share of an iteration is
+                    ("reference_batch_64_10_epochs", dict(episodes=max(64, episodes // 8), batch_size=64, epochs=10), "hip"),
                     ("batch_512", dict(episodes=episodes, batch_size=512, epochs=1), "hip"),
                     # the same loop on the stock PyTorch step (MIOpen convolutions, replayed as a HIP graph): the checker, timed beside it
                     ("reference_batch_64_stock_pytorch", dict(episodes=max(64, episodes // 8), batch_size=64, epochs=1), "torch")]
+    if only:
+        variants = [v for v in variants if v[0] in only]
     base.DEFAULT_MODELS_PATH = tempfile.mkdtemp() + "/"
     out = {"workload": f"Othello 8x8 trainer loop: self-play ({sims} sims/move) + symmetry augmentation + SGD (momentum 0.9, weight decay 1e-4, "
                        f"ExponentialLR 0.9) + weight hand-off + {eval_episodes} arena games against the previous network", "n_gpus": job.world,
@@ -550,18 +644,71 @@ def run_latency(sims):
     return out
 
 
+def run_config1(sims=100, games=2):
+    """BASELINE.json configs[0]: TicTacToe, rollout-mode MCTSPlayer(n_sim=100) on both sides, temp 0, 2 self-play games, timed game by
+    game in the SelfPlayTimer idiom (timers.py:42-76) through the reference's plugin surface -- Board + Player objects, the tree
+    on the GPU (one engine slot, k_rollout_step: one launch per simulation).  Reference: 0.159 / 0.171 s."""
+    from alphazero_amd.games.tictactoe import TicTacToeBoard
+    from alphazero_amd.players import MCTSPlayer
+    np.random.seed(0)
+    board, player = TicTacToeBoard(), MCTSPlayer(n_sim=sims)
+    out = []
+    for g in range(games + 1):  # game 0 is the warm-up (engine creation, kernels loaded), not reported
+        board.reset()
+        player.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plies = 0
+        while not board.is_game_over():
+            move = player.get_move(board)[0]
+            board.play_move(move)
+            player.apply_move(move, player=-board.player)
+            plies += 1
+        torch.cuda.synchronize()
+        if g:
+            out.append({"seconds": time.perf_counter() - t0, "plies": plies, "winner": int(board.get_winner())})
+    if player.mct._engine is not None:
+        player.mct._engine.close()
+    return {"workload": f"TicTacToe, MCTSPlayer(n_sim={sims}, rollout mode) on both sides, temp 0, {games} self-play games (SelfPlayTimer idiom)",
+            "games": out, "seconds_per_game_mean": float(np.mean([g["seconds"] for g in out])),
+            "reference_seconds": [0.159, 0.171], "reference_where": "build container, 1 core (BASELINE.md section 2)"}
+
+
+def run_saturated(job, games, sims, steps, warmup, first_wave):
+    """the headline's workload at `games` concurrent games per GPU (weak scaling at N > 1, all-gather included): where the
+    rate-against-batch curve has flattened"""
+    w = Workload("saturated", "othello", games, sims)
+    r = timed_waves(job, w, steps, warmup, first_wave=first_wave)
+    total = steps * games * job.world
+    out = {"workload": w.desc, "concurrent_games": games, "n_gpus": job.world, "value": total / r["dt"], "unit": "games/s",
+           "examples_per_sec": r["samples"] / r["dt"], "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * r["dt"] / steps,
+           "per_rank_ms_per_step": r["per_rank_ms_per_step"], "per_rank_gather_ms_per_step": r["per_rank_gather_ms_per_step"], "dtype": "f32"}
+    if job.world > 1:
+        dist.barrier()
+    if job.rank == 0:
+        out["roofline"] = w.profiled_wave((first_wave + warmup + steps) * games * job.world, timed_evals=r["evals_all"] / job.world, timed_seconds=r["dt"])
+    w.close()
+    if job.world > 1:
+        dist.barrier()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=32768, help="concurrent games (engine slots) per GPU of the headline run")
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games (engine slots) per GPU of the headline run: BASELINE configs[1] / [2]")
     ap.add_argument("--waves", type=int, default=1, help="games per step per GPU = waves x games (finished slots are refilled)")
     ap.add_argument("--sims", type=int, default=100)
+    ap.add_argument("--saturated-games", type=int, default=32768, help="concurrent games per GPU of the `saturated` extra (0: skip)")
     ap.add_argument("--config3-total", type=int, default=32768, help="N > 1: concurrent games of config3, sharded over the ranks")
+    ap.add_argument("--config4-games", type=int, default=8192)
     ap.add_argument("--config5-episodes", type=int, default=4096, help="episodes per iteration of the config5 trainer loop")
+    ap.add_argument("--config5-eval-episodes", type=int, default=64)
+    ap.add_argument("--config5-variants", default="", help="comma-separated subset of the config5 variants (default: all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-literal-configs", action="store_true", help="skip the config2 / config3 / config4 / config5 objects")
+    ap.add_argument("--no-literal-configs", action="store_true", help="skip the saturated / config1 / config3 / config4 / config5 / latency objects")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -574,12 +721,19 @@ def main():
     dry = os.environ.get("AZ_BENCH_DRYRUN")
     if dry:
         # launcher rehearsal without a GPU (tests/test_dist.py): the ranks only rendezvous over gloo, reduce one number and rank 0 prints
-        # a stub line; "fail:<rank>" makes that rank exit non-zero after the rendezvous (the parent must then stop the others)
+        # a stub line; "fail:<rank>" makes that rank exit non-zero after the rendezvous (the parent must then stop the others);
+        # "hang:<rank>" makes every OTHER rank wait forever at a barrier that rank never reaches (the parent must kill them)
         dist.init_process_group("gloo")
         t = torch.tensor([float(job.rank + 1)])
         dist.all_reduce(t)
         if dry.startswith("fail:") and int(dry.split(":")[1]) == job.rank:
             sys.exit(7)
+        if dry.startswith("hang:"):
+            if int(dry.split(":")[1]) == job.rank:
+                sys.exit(7)
+            import signal
+            signal.signal(signal.SIGTERM, signal.SIG_IGN)  # a rank stuck in a device wait does not react to SIGTERM either
+            time.sleep(3600)
         dist.barrier()
         if job.rank == 0:
             print(json.dumps({"dryrun": True, "n_gpus": job.world, "sum_of_ranks_plus_one": float(t.item())}), flush=True)
@@ -603,12 +757,16 @@ def main():
 
     if rank == 0:
         games = args.steps * G * world
+        literal = args.games == 4096 and args.sims == 100 and args.waves == 1
         out = {
             "metric": "self-play games/sec (whole node), Othello 8x8 @100 sims/move", "value": games / dt, "unit": "games/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": w.desc, "games_per_gpu_per_step": G, "concurrent_games_per_gpu": w.G, "sims_per_move": args.sims,
-                       "parallelism": f"game-sharded x{world}", "timed_region": "engine as shipped: searches replayed as HIP graphs, no event recording"},
+            "config": {"workload": (f"BASELINE configs[{1 if world == 1 else 2}] literal: " if literal else "") +
+                                   f"Othello 8x8, {w.G} concurrent games/GPU, {args.sims} sims/move, {world} MI355X",
+                       "concurrent_games_per_gpu": w.G, "games_per_gpu_per_step": G, "sims_per_move": args.sims,
+                       "parallelism": f"game-sharded x{world}" + (", RCCL sample all-gather per wave" if world > 1 else ""),
+                       "examples_per_sec": samples / dt, "us_per_lockstep": 1e3 * 1e3 * dt / args.steps / max(1, st["lockstep_iters"])},
             "examples_per_sec": samples / dt, "sims_per_sec": samples * args.sims / dt,
             "plies_per_game": samples / games, "net_evals_last_step": st["net_evals"], "lockstep_iters_last_step": st["lockstep_iters"],
             "graph_replays": st["graph_replays"], "max_tree_nodes_per_game": st["max_nodes_used"],
@@ -619,37 +777,68 @@ def main():
         dist.barrier()
     # the roofline's per-kernel times: one extra step, profiled, outside the timed region (rank 0; the others idle at the barrier)
     roof = w.profiled_wave((args.warmup + args.steps) * G * world + rank * G, timed_evals=r["evals_all"] / world, timed_seconds=dt) if rank == 0 else None
+    kstep_key = f"othello_{w.G}"
     w.close()
     if world > 1:
         dist.barrier()
-    config3 = config5 = None
+    saturated = config1 = config3 = config4 = config5 = latency = None
     if not args.no_literal_configs:
-        if world > 1:
+        if args.saturated_games and args.saturated_games != args.games:
+            saturated = run_saturated(job, args.saturated_games, args.sims, steps=2, warmup=1, first_wave=1000)
+        if world > 1 and args.config3_total // world != args.games:
             config3 = run_config3(job, args.config3_total, args.sims, steps=2, warmup=1)
-        config5 = run_config5(job, args.config5_episodes, args.sims)
+        if world == 1:
+            # Othello games all last 60-65 plies: one synchronised wave per step keeps 92 % of the leaf rows filled (the rest are
+            # terminal leaves, which need no evaluation).  Connect4 games last 18-42 plies: finished slots are refilled and a
+            # step plays 8 x 8192 games, so that the drain at the end of a step (its length is one game) is amortised
+            config4 = run_single("config4", "connect4", args.config4_games, 200, steps=2, warmup=1, waves=8)
+            config1 = run_config1()
+        config5 = run_config5(job, args.config5_episodes, args.sims, eval_episodes=args.config5_eval_episodes, only=[v for v in args.config5_variants.split(",") if v] or None)
+        if world == 1:
+            latency = run_latency(args.sims)
     if rank == 0:
-        out["roofline"] = roof
+        cfg = out["config"]
+        cfg["end_to_end_frac"] = roof.get("end_to_end_frac")
+        if saturated is not None:
+            c = compact(saturated)
+            cfg.update({"saturated_concurrent_games_per_gpu": args.saturated_games, "saturated_games_per_sec": c["games_per_sec"],
+                        "saturated_end_to_end_frac": c["end_to_end_frac"], "saturated_dominant_kernel": c["dominant_kernel"],
+                        "saturated_dominant_frac": c["dominant_frac"], "saturated_forward_frac": c["forward_frac"]})
+        if config4 is not None:
+            c = compact(config4)
+            cfg.update({"config4_games_per_sec": c["games_per_sec"], "config4_end_to_end_frac": c["end_to_end_frac"],
+                        "config4_dominant_kernel": c["dominant_kernel"], "config4_dominant_frac": c["dominant_frac"],
+                        "config4_workload": f"Connect4 6x7, {args.config4_games} concurrent games, 200 sims/move"})
+        if config3 is not None:
+            cfg.update({"config3_games_per_sec": config3["value"], "config3_concurrent_games_per_gpu": config3["concurrent_games_per_gpu"],
+                        "config3_end_to_end_frac_per_gpu": config3["end_to_end_frac_per_gpu"]})
+        if config1 is not None:
+            cfg.update({"config1_device_seconds_game0": config1["games"][0]["seconds"], "config1_device_seconds_game1": config1["games"][1]["seconds"]})
+        if config5 is not None:
+            v10 = config5["variants"].get("reference_batch_64_10_epochs")
+            if v10:
+                cfg.update({"config5_10_epochs_iteration_seconds": v10["iterations"][1]["iteration_seconds"],
+                            "config5_10_epochs_sgd_share": v10["iterations"][1]["sgd_share"],
+                            "config5_10_epochs_sgd_ms_per_step": v10["iterations"][1]["sgd_ms_per_step"]})
+        cfg["timed_region"] = "engine as shipped: HIP-graph replays, no event recording"
+        if saturated is not None and saturated.get("roofline"):
+            roof["saturated_frac"], roof["saturated_end_to_end_frac"] = saturated["roofline"]["frac"], saturated["roofline"].get("end_to_end_frac")
+            roof["saturated_kernel"] = saturated["roofline"]["kernel"][:40]
+        if config4 is not None:
+            roof["config4_frac"], roof["config4_end_to_end_frac"] = config4["roofline"]["frac"], config4["roofline"].get("end_to_end_frac")
+            roof["config4_kernel"] = config4["roofline"]["kernel"][:40]
+        out["roofline"] = ordered(roof, ROOF_FIRST + ["saturated_frac", "saturated_end_to_end_frac", "config4_frac", "config4_end_to_end_frac"])
         sims_per_gpu = samples * args.sims / dt / world
         tree = {"algorithmic_bytes_per_sim": 919, "achieved": sims_per_gpu * 919 / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": sims_per_gpu * 919 / 8e12, "note": "per GPU, whole path: the tree kernels are a few % of a step, the path is bound by the network's MFMA work"}
         kfile, kwhy = stamped("kstep_counters.json")  # k_step<true,true>: duration + FETCH_SIZE / WRITE_SIZE passes (tools/refresh_profiles.sh)
-        tree["k_step"] = kfile.get(f"othello_{w.G}") if kfile else None
+        tree["k_step"] = kfile.get(kstep_key) if kfile else None
         tree["k_step_source"] = kwhy
         out["tree_hbm"] = tree
-        if config3 is not None:
-            out["config3"] = config3
-        if world == 1 and not args.no_literal_configs:
-            # Othello games all last 60-65 plies: one synchronised wave per step keeps 92 % of the leaf rows filled (the rest are
-            # terminal leaves, which need no evaluation).  Connect4 games last 18-42 plies: finished slots are refilled and a
-            # step plays 8 x 8192 games, so that the drain at the end of a step (its length is one game) is amortised
-            out["config2"] = run_single("config2", "othello", 4096, 100, steps=3, warmup=1, waves=1)
-            out["config4"] = run_single("config4", "connect4", 8192, 200, steps=2, warmup=1, waves=8)
-        if config5 is not None:
-            out["config5"] = config5
-        if world == 1 and not args.no_literal_configs:
-            out["latency"] = run_latency(args.sims)
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
+        for name, obj in (("saturated", saturated), ("config1", config1), ("config3", config3), ("config4", config4), ("config5", config5),
+                          ("latency", latency), ("cpu_baseline", cpu)):
+            if obj is not None:
+                out[name] = obj
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -219,9 +219,13 @@ int az_trainer_store(az_trainer *t, const char *name, float *d_dst, int64_t nume
 int az_trainer_begin(az_trainer *t, float lr, float momentum, float weight_decay, float dropout_p, uint32_t seed, void *stream);
 int az_trainer_set_lr(az_trainer *t, float lr, void *stream); /* ExponentialLR between epochs (trainer.py:327, 381) */
 /* n_steps steps: step s trains on rows d_perm[s*B .. s*B+B) of the sample arrays (d_state int8 [S][H*W] = grid * player,
- * d_pi float [S][A], d_z int8 [S]) and writes its losses to d_loss_pi[s], d_loss_v[s] (trainer.py:352-353).  Asynchronous. */
-int az_trainer_steps(az_trainer *t, const int8_t *d_state, const float *d_pi, const int8_t *d_z, const int64_t *d_perm,
+ * d_pi float [S][A], d_z int8 [S], S = n_samples = len(memory) of trainer.py:288-318, whose indices d_perm holds) and writes its
+ * losses to d_loss_pi[s], d_loss_v[s] (trainer.py:352-353).  Asynchronous.  A permutation entry outside [0, n_samples) is never
+ * used as an address: the kernels train that batch slot on row 0 and raise a sticky flag, reported as AZ_EINVAL by az_trainer_check
+ * (which waits for the enqueued steps) or by the next az_trainer_steps call. */
+int az_trainer_steps(az_trainer *t, const int8_t *d_state, const float *d_pi, const int8_t *d_z, int64_t n_samples, const int64_t *d_perm,
                      int32_t n_steps, int32_t B, float *d_loss_pi, float *d_loss_v, void *stream);
+int az_trainer_check(az_trainer *t);
 /* test access: device pointer and element count of a workspace buffer of the last step ("c1".."c4", "y1", "h1", "dz1", ...) */
 int az_trainer_debug(az_trainer *t, const char *name, void **d_ptr, int64_t *numel);
 

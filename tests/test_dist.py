@@ -113,6 +113,61 @@ def test_trainer_setup_hands_rank0_weights_to_every_rank():
     assert all(torch.equal(ret[0][k], want[k]) for k in want)
 
 
+def _worker8(rank, world, port, ret):
+    """the N = 8 control flow of a job with FEWER units than ranks: 5 self-play episodes and 5 arena rounds over 8 ranks -> ranks
+    5, 6, 7 play nothing, hold no samples and still take part in every collective (trainer.self_play, BatchedArena.play_games,
+    bench.py's per-rank rows)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from alphazero_amd.dist import all_gather_samples, broadcast_state_dict, gather_sharded_rows, rank_game_range, shard_range
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    n = 5
+    lo, cnt, per = shard_range(n, rank, world)
+    ok &= per == 1 and cnt == (1 if rank < n else 0) and lo == min(rank, n)
+    # self-play: episode e yields 3 + e samples, every sample tagged with its episode
+    S = sum(3 + e for e in range(lo, lo + cnt))
+    tag = torch.cat([torch.full((3 + e,), e, dtype=torch.int32) for e in range(lo, lo + cnt)]) if cnt else torch.zeros(0, dtype=torch.int32)
+    smp = {"state": tag.to(torch.int8).view(-1, 1, 1).expand(S, 8, 8).contiguous(), "pi": tag.float().view(-1, 1).expand(S, 65).contiguous(),
+           "z": tag.to(torch.int8), "meta": torch.stack([tag] * 4, dim=1) if S else torch.zeros((0, 4), dtype=torch.int32)}
+    out = all_gather_samples(smp)
+    want = torch.cat([torch.full((3 + e,), e, dtype=torch.int32) for e in range(n)])
+    ok &= torch.equal(out["meta"][:, 0], want) and torch.equal(out["z"], want.to(torch.int8)) and out["state"].shape == (len(want), 8, 8)
+    ok &= bool((out["pi"][:, 7] == want.float()).all())
+    # arena: (winner, score) rows of this rank's rounds, padded to `per`
+    res = torch.full((per, 2), -2, dtype=torch.int32)
+    if cnt:
+        res[:cnt, 0] = torch.arange(lo, lo + cnt, dtype=torch.int32) % 3 - 1
+        res[:cnt, 1] = 10 * torch.arange(lo, lo + cnt, dtype=torch.int32)
+    allr = gather_sharded_rows(res, n, force=True)
+    ok &= allr.shape == (n, 2) and torch.equal(allr[:, 1], 10 * torch.arange(n, dtype=torch.int32)) and torch.equal(allr[:, 0], torch.arange(n, dtype=torch.int32) % 3 - 1)
+    # 17 units over 8 ranks: blocks of 3, the last rank is empty, rank 5 holds two
+    lo2, cnt2, per2 = shard_range(17, rank, world)
+    blk = torch.full((per2, 1), -1, dtype=torch.int64)
+    blk[:cnt2, 0] = torch.arange(lo2, lo2 + cnt2)
+    ok &= per2 == 3 and torch.equal(gather_sharded_rows(blk, 17, force=True)[:, 0], torch.arange(17))
+    # weights: every rank starts elsewhere, rank 0's arrive
+    torch.manual_seed(100 + rank)
+    lin = torch.nn.Linear(4, 4)
+    broadcast_state_dict(lin, src=0)
+    torch.manual_seed(100)
+    ok &= torch.equal(lin.weight, torch.nn.Linear(4, 4).weight)
+    first, g = rank_game_range(rank, world, 4096, wave=2)
+    ret[rank] = (bool(ok), first, g)
+    dist.destroy_process_group()
+
+
+def test_world8_with_fewer_units_than_ranks():
+    """VERDICT r3 item 3 (CPU half): the sharding arithmetic and every collective of the multi-GPU path at world size 8, including
+    ranks with zero episodes / zero arena rounds / zero samples"""
+    world = 8
+    ret = mp.Manager().dict()
+    mp.spawn(_worker8, args=(world, 29541, ret), nprocs=world, join=True)
+    assert all(ret[r][0] for r in range(world)), {r: ret[r][0] for r in range(world)}
+    ids = sorted(ret[r][1] for r in range(world))
+    assert ids == [(2 * 8 + r) * 4096 for r in range(8)]  # config 3: 8 x 4096 disjoint game-id blocks per wave
+
+
 def _run_bench(env_extra, n):
     import subprocess
     env = dict(os.environ, **env_extra)
@@ -138,3 +193,48 @@ def test_bench_launcher_fails_when_a_rank_fails():
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert "rank 2 exited with 7" in p.stderr
+
+
+def test_bench_launcher_with_eight_ranks():
+    import json
+    p = _run_bench({"AZ_BENCH_DRYRUN": "1"}, 8)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["sum_of_ranks_plus_one"] == 36.0
+
+
+def test_bench_launcher_kills_ranks_that_ignore_sigterm():
+    """after a rank fails the others get terminate() and, past the grace period, kill(): a rank stuck in a device wait
+    (here: one that ignores SIGTERM and sleeps) must not keep the launcher -- or its GPU -- forever"""
+    import time
+    t0 = time.time()
+    p = _run_bench({"AZ_BENCH_DRYRUN": "hang:1", "AZ_BENCH_KILL_GRACE_S": "2"}, 3)
+    assert p.returncode != 0 and time.time() - t0 < 120
+    assert "rank 1 exited with 7" in p.stderr
+
+
+def test_bench_launcher_stops_its_ranks_when_it_is_terminated():
+    """SIGTERM to the launcher (a harness time limit): the ranks it started are gone afterwards"""
+    import signal
+    import subprocess
+    import time
+    env = dict(os.environ, AZ_BENCH_DRYRUN="hang:99", AZ_BENCH_KILL_GRACE_S="2")  # no rank exits by itself: all sleep
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    kids = []
+    for _ in range(300):
+        try:
+            kids = [int(x) for x in open(f"/proc/{p.pid}/task/{p.pid}/children").read().split()]
+        except OSError:
+            kids = []
+        if len(kids) == 2:
+            break
+        time.sleep(0.1)
+    assert len(kids) == 2
+    time.sleep(5)  # let the ranks reach their sleep (SIGTERM ignored from then on)
+    p.send_signal(signal.SIGTERM)
+    p.communicate(timeout=120)
+    assert p.returncode == 130
+    time.sleep(0.5)
+    assert not any(os.path.exists(f"/proc/{k}") and "bench.py" in open(f"/proc/{k}/cmdline").read() for k in kids)

@@ -284,10 +284,12 @@ def test_graphed_sgd_equals_eager_sgd(tmp_path, monkeypatch):
     tr.setup()
     tr.self_play(0)
     out = {}
+    tr.sgd_backend = "torch"  # the stock PyTorch step, eager and graph-replayed (the default backend is the hand-written HIP step)
     for mode in (False, True):
         tr.graph_sgd = mode
         torch.manual_seed(11)
         tr.optimize_network(0)
+        assert tr.sgd_backend_used == "torch"
         out[mode] = ({k: v.detach().clone() for k, v in tr.nn_twin.state_dict().items()}, tr.loss_values[0])
     n_steps = tr.device_memory["z"].shape[0] // 128
     assert n_steps > 8 and len(out[True][1][0]["pi"]) == n_steps and len(out[True][1][0]["v"]) == n_steps
@@ -307,7 +309,8 @@ def test_graphed_sgd_equals_eager_sgd(tmp_path, monkeypatch):
 @pytest.mark.parametrize("tag", ["tictactoe", "connect4", "othello6", "othello8"])
 @pytest.mark.parametrize("graphed", [False, True])
 def test_device_sgd_matches_reference_fixture(tag, graphed):
-    """golden G6 on the GPU: optimize_network on DEVICE-resident samples (eager and as a replayed HIP graph) logs the
+    """golden G6 on the GPU through the STOCK PyTorch step (sgd_backend "torch": the checker of the hand-written step, which
+    tests/test_gpu_train_step.py holds to the same fixture): optimize_network on DEVICE-resident samples (eager and as a replayed HIP graph) logs the
     per-batch losses the reference's CPU loop logged (same initial weights, same batches in the same order, dropout 0)
     over two epochs, and ends with the same weights.  float32 on two devices: the first six steps agree to 5e-5 (a wrong
     momentum or learning rate shows from step 3 on at 1e-2); the small nets stay within 2e-4 over both epochs and end with
@@ -322,7 +325,7 @@ def test_device_sgd_matches_reference_fixture(tag, graphed):
     extra = {"board_size": n} if game == "othello" else {}
     cfg = CONFIGS_REGISTER[game](epochs=int(fx["epochs"]), batch_size=int(fx["batch_size"]), device="cuda", **extra)
     tr = AlphaZeroTrainer(verbose=False)
-    tr.config, tr.game, tr.graph_sgd = cfg, game, graphed
+    tr.config, tr.game, tr.graph_sgd, tr.sgd_backend = cfg, game, graphed, "torch"
     net = NETWORKS_REGISTER[game](config=cfg)
     shapes = {str(k): ast.literal_eval(str(v)) for k, v in zip(net_fx["shape_keys"], net_fx["shape_vals"])}
     net.load_state_dict({k: torch.tensor(v) for k, v in cf.closed_form_state_dict(shapes).items()})
@@ -341,6 +344,7 @@ def test_device_sgd_matches_reference_fixture(tag, graphed):
     tr._permutation = reference_order
     tr.loss_values = {}
     tr.optimize_network(0)
+    assert tr.sgd_backend_used == "torch"
     for e in range(int(fx["epochs"])):
         for k in ("pi", "v"):
             got = np.array(tr.loss_values[0][e][k])

@@ -192,7 +192,16 @@ def test_search_begin_and_end_come_in_pairs():
         eng.search_begin(4)
         with pytest.raises(AzError):
             eng.search_begin(4)  # the first one is still open
+        # ... and so is every other entry point of this engine until the search has been ended: they would reorder the
+        # host-side state of the search in flight and its error flags would never be read
+        for call in (lambda: eng.search(4), eng.advance, lambda: eng.play([0, 0, 0, 0]), lambda: eng.set_roots(board, np.ones(4, np.int8)),
+                     lambda: eng.root_children(0), lambda: eng.nodes_used(0), lambda: eng.grow_pools(1 << 15), eng.best_moves, lambda: eng.run(4),
+                     lambda: eng.samples()):
+            with pytest.raises(AzError, match="has not been ended"):
+                call()
         eng.search_end()
+        a, n, _, _, rootn = eng.root_children(0)  # the search itself was not disturbed
+        assert rootn == 4 == int(np.sum(n))
         with pytest.raises(ValueError):
             eng.pair_with(eng)
     finally:

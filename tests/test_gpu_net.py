@@ -42,8 +42,10 @@ def test_bit_exact_vs_oracle(tag):
     fx, sd, onet, hnet = nets(tag)
     grids, players, _ = O.random_positions(gid, H, W, 77, 40, 1500)
     canon = (grids * players[:, None]).astype(np.float32)
+    if len(players) % 64 == 0:  # a ragged row count: the last workgroup of every kernel is partly filled
+        canon, players = canon[:-1], players[:-1]
     B = len(players)
-    assert B > 300 and B % 64 != 0 or True
+    assert B > 300 and B % 64 != 0
     probs, v = hnet.forward(torch.as_tensor(canon, device="cuda"))
     oprobs, ov = onet.forward(canon)
     assert np.array_equal(probs.cpu().numpy(), oprobs), np.abs(probs.cpu().numpy() - oprobs).max()

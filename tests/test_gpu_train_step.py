@@ -27,21 +27,29 @@ pytestmark = pytest.mark.gpu
                                                  # boards on 256 workgroups (one or two boards each: unequal counts in the statistics partials)
                                                  ("othello8", 48, 2, 0.3), ("othello6", 80, 2, 0.0), ("connect4", 144, 2, 0.3), ("othello8", 320, 1, 0.3)])
 def test_training_step_equals_torch_autograd(tag, B, steps, dropout):
+    """ALL three data seeds must be clean.  The one exception a float32-against-float64 comparison has by nature: a ReLU input that
+    is zero to float32 rounding in the float64 run may take the other branch in the float32 step, and that one unit's difference
+    spreads downstream.  tools/check_train_step.py::relu_ties finds such units in the float64 run; a seed may only be off when the
+    float64 run itself has one, and the (case, seed) pairs where that happens are listed by hand in KNOWN_RELU_TIES and counted."""
     import check_train_step as C
     for seed in (0, 1, 2):
-        # a pre-activation that is zero to rounding may pass the ReLU in float32 and not in float64 (or the other way round): one unit
-        # of one row then differs and the difference spreads downstream.  Such a tie belongs to the data, not to the kernels: a real
-        # defect fails for every seed
         rows = C.report(tag, B, steps, dropout, verbose=False, seed=seed)
         bad = [(n, e, s) for n, e, s in rows if e > 2e-4 * max(s, 1e-3) + 1e-6]
-        if not bad:
-            break
-    assert not bad, bad[:8]
+        if (tag, B, steps, dropout, seed) in KNOWN_RELU_TIES:
+            assert C.report.ties, ("listed as a ReLU tie, but the float64 run has no unit on a kink", tag, B, steps, dropout, seed)
+            continue
+        assert not bad, (seed, C.report.ties, bad[:8])
     names = {n for n, _, _ in rows}
     if tag != "tictactoe":
         assert {"step0.c4", "step0.dy1", "step0.dz1", "step0.dlog.policy", "final.conv1.weight", "final.fc_bn2.running_var", "final.bn3.num_batches_tracked"} <= names
     else:
         assert {"step0.loss_pi", "final.fc1.weight", "final.bn2.running_var", "final.bn1.num_batches_tracked", "final.fc_value.bias"} <= names
+
+
+# (tag, batch, steps, dropout, seed) whose float64 run has a ReLU input on the kink AND whose float32 step resolves it the other way
+# (found with tools/list_relu_ties.py on an MI355X; 19 cases x 3 seeds = 57 runs)
+KNOWN_RELU_TIES = set()
+assert len(KNOWN_RELU_TIES) <= 3
 
 
 def _fixture_trainer(tag, backend):
@@ -74,29 +82,59 @@ def _fixture_trainer(tag, backend):
     return tr, fx
 
 
+def _float64_trajectory(tag, fx):
+    """the SAME step sequence (initial weights, batches, order, learning-rate schedule) in float64 on the CPU with torch autograd:
+    the trajectory both float32 runs -- the reference's (golden G6) and the hand-written step's -- are roundings of"""
+    tr, _ = _fixture_trainer(tag, "torch")
+    net = tr.nn.cpu().double().train()
+    m = {k: v.cpu() for k, v in tr.device_memory.items()}
+    bs, epochs = int(fx["batch_size"]), int(fx["epochs"])
+    opt = torch.optim.SGD(net.parameters(), lr=tr.config.learning_rate, momentum=0.9, weight_decay=0.0001)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+    out = {}
+    for e in range(epochs):
+        nb = m["z"].shape[0] // bs
+        perm = tr._permutation(m["z"].shape[0], "cpu")[: nb * bs].view(nb, bs)
+        out[e] = {"pi": [], "v": []}
+        for rows in perm:
+            x, pi, z = m["state"][rows].double(), m["pi"][rows].double(), m["z"][rows].double().unsqueeze(1)
+            opt.zero_grad()
+            log_p, v = net(x)
+            loss_pi, loss_v = -torch.sum(pi * log_p) / bs, torch.sum((v - z) ** 2) / bs
+            (loss_pi + loss_v).backward()
+            opt.step()
+            out[e]["pi"].append(float(loss_pi)); out[e]["v"].append(float(loss_v))
+        sched.step()
+    return out
+
+
 @pytest.mark.parametrize("tag", ["tictactoe", "connect4", "othello6", "othello8"])
 def test_hand_written_step_matches_the_reference_fixture(tag):
     """golden G6: the per-batch losses the REFERENCE's optimize_network logged (same initial weights, same batches in the same order,
     dropout 0).  First six steps of epoch 0 within 5e-5 (a wrong momentum / learning rate / weight decay shows from step 3 on at
-    1e-2); the rest of the trajectory: Connect4Net within 2e-4 and the same final weights; the OthelloNets within 0.05 over epoch 0 and
-    the epoch mean within 25 % afterwards (momentum SGD at lr 0.1 amplifies float32 rounding differences between any two
-    implementations: the stock MIOpen path is held to the same bounds in tests/test_gpu_api.py)"""
+    1e-2); Connect4Net / TicTacToeNet within 2e-4 over the whole trajectory and the same final weights.  The OthelloNets (momentum SGD
+    at lr 0.1 amplifies float32 rounding step by step) are held against the float64 run of the same sequence: at every step the
+    hand-written step may be at most twice as far from the float64 trajectory as the reference's own float32 run has been so far
+    (|hip - f64|_k <= 2 max_{j<=k} |ref - f64|_j + 5e-5) -- two roundings of one trajectory, not "25 % of the epoch mean" """
     tr, fx = _fixture_trainer(tag, "hip")
     tr.optimize_network(0)
     assert tr.sgd_backend_used == "hip"
-    for e in range(int(fx["epochs"])):
-        for k in ("pi", "v"):
+    f64 = _float64_trajectory(tag, fx) if tag.startswith("othello") else None
+    for k in ("pi", "v"):
+        seen = 0.0
+        for e in range(int(fx["epochs"])):
             got, ref = np.array(tr.loss_values[0][e][k]), fx[f"{k}_loss_{e}"]
             assert got.shape == ref.shape
             err = np.abs(got - ref)
             if e == 0:
                 assert err[:6].max() < 5e-5, (tag, k, err[:6])
-            if tag in ("connect4", "tictactoe"):
+            if f64 is None:
                 assert err.max() < 2e-4, (tag, e, k, err.max())
-            elif e == 0:
-                assert err.max() < 0.05, (tag, e, k, err.max())
-            else:
-                assert abs(got.mean() - ref.mean()) < 0.25 * ref.mean() + 0.03, (tag, e, k, got.mean(), ref.mean())
+                continue
+            exact = np.array(f64[e][k])
+            for i in range(len(got)):
+                seen = max(seen, abs(ref[i] - exact[i]))
+                assert abs(got[i] - exact[i]) <= 2 * seen + 5e-5, (tag, k, e, i, got[i], ref[i], exact[i], seen)
     sd = {k: v.cpu().numpy() for k, v in tr.nn_twin.state_dict().items()}
     if tag in ("connect4", "tictactoe"):
         assert np.abs(sd["fc1.weight"][:64] - fx["fc1_weight"]).max() < 1e-4
@@ -124,10 +162,32 @@ def test_backends_are_selectable_and_unsupported_shapes_use_the_stock_step():
         train_step.HipTrainStep(tr.nn, max_batch=520)
     ts = train_step.HipTrainStep(tr.nn, max_batch=32)
     m = tr.device_memory
-    bad = torch.full((32,), m["z"].shape[0], dtype=torch.int64, device="cuda")  # one past the last row
-    with pytest.raises(ValueError):
-        ts.steps(m["state"], m["pi"], m["z"], bad, 1, 32, torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda"))
+    # a permutation entry outside the sample arrays (one past the last row, a negative one): the kernels clamp it and raise the flag
+    # that check() -- or the next steps() -- turns into the ValueError; the GPU does not fault and the trainer stays usable
+    ts.load(tr.nn)
+    ts.begin(0.01, 0.9, 1e-4, 0.0, seed=1)
+    good = torch.arange(32, dtype=torch.int64, device="cuda")
+    lp, lv = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    for wrong in (m["z"].shape[0], -1, 1 << 40):
+        bad = good.clone()
+        bad[7] = wrong
+        ts.steps(m["state"], m["pi"], m["z"], bad, 1, 32, lp, lv)
+        with pytest.raises(ValueError, match="permutation entry"):
+            ts.check()
+        ts.check()  # reported once, then clear
+    ts.steps(m["state"], m["pi"], m["z"], bad, 1, 32, lp, lv)
+    with pytest.raises(ValueError, match="permutation entry"):  # nobody called check(): the next call reports it
+        ts.steps(m["state"], m["pi"], m["z"], good, 1, 32, lp, lv)
+    ts.steps(m["state"], m["pi"], m["z"], good, 1, 32, lp, lv)
+    ts.check()
+    assert torch.isfinite(lp).all() and torch.isfinite(lv).all()
     ts.close()
+    # a module that is not the reference's architecture: not for the hand-written step
+    from alphazero_amd.games.othello import OthelloNet
+    odd = OthelloNet(n=8)
+    assert train_step.supports(odd, 64)
+    odd.fc2 = torch.nn.Linear(1024, 256)
+    assert not train_step.supports(odd, 64)
 
 
 def test_dropout_law_and_determinism():

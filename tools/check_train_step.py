@@ -59,12 +59,16 @@ def torch_step(net, x, pi, z, bs, masks=None, p=0.0):
         h = F.relu(b)
     h = h.reshape(-1, net.fc1_input_size)
     y1 = k("y1", net.fc1(h))
-    h1 = F.relu(net.fc_bn1(y1))
+    a1 = net.fc_bn1(y1)
+    keep["a1"] = a1
+    h1 = F.relu(a1)
     if masks is not None:
         h1 = h1 * masks[0] / (1.0 - p)
     h1 = k("h1", h1)
     y2 = k("y2", net.fc2(h1))
-    h2 = F.relu(net.fc_bn2(y2))
+    a2 = net.fc_bn2(y2)
+    keep["a2"] = a2
+    h2 = F.relu(a2)
     if masks is not None:
         h2 = h2 * masks[1] / (1.0 - p)
     h2 = k("h2", h2)
@@ -81,8 +85,25 @@ def nhwc(t):  # torch [B, C, H, W] -> the step's [B, H*W, C]
     return t.permute(0, 2, 3, 1).reshape(t.shape[0], -1, t.shape[1])
 
 
+def relu_ties(keep, rel=2e-6):
+    """ReLU inputs of the float64 run that are zero to float32 rounding (|x| < rel * max|x| of their layer): such a unit may take the
+    other branch in the float32 step, and the one-unit difference then spreads downstream -- a property of the data, not of the
+    kernels.  -> [(layer, count, smallest |x| / max|x|)] of the layers that have any"""
+    out = []
+    for name in ("b1", "b2", "b3", "b4", "a1", "a2"):
+        if name in keep:
+            x = keep[name].detach().abs()
+            m = float(x.max())
+            n = int((x < rel * m).sum())
+            if n:
+                out.append((name, n, float(x.min()) / m))
+    return out
+
+
 def report(tag="othello8", B=64, steps=3, dropout=0.0, verbose=True, seed=0):
+    """-> rows (buffer, max abs error, scale); report.ties = relu_ties() of every step (empty: no unit of the run sits on a ReLU kink)"""
     from alphazero_amd.train_step import HipTrainStep
+    report.ties = []
     net = make_net(tag, seed)
     S = B * steps + 7
     state, pi, z = make_samples(net, S, seed=1 + 17 * seed)
@@ -130,6 +151,7 @@ def report(tag="othello8", B=64, steps=3, dropout=0.0, verbose=True, seed=0):
             masks = ((hip.debug("h1", (hip.max_batch, F1))[:B] != 0).double().cpu(), (hip.debug("h2", (hip.max_batch, F2))[:B] != 0).double().cpu())
         opt.zero_grad()
         t_pi, t_v, keep = torch_step(ref, x, pi[rws].double(), z[rws].double().unsqueeze(1), B, masks, dropout)
+        report.ties += [(s,) + t for t in relu_ties(keep)]
         if s in (0, steps - 1) and hasattr(net, "conv1"):
             pre = f"step{s}."
             for i in range(4):
@@ -164,3 +186,4 @@ if __name__ == "__main__":
     bad = [(n, e, s) for n, e, s in rows if e > 2e-4 * max(s, 1e-3) + 1e-6]
     print("WORST", sorted(rows, key=lambda r: -r[1] / max(r[2], 1e-3))[:5])
     print("BAD", bad[:20], len(bad))
+    print("RELU TIES (step, layer, units, smallest |x| / max|x|)", report.ties)
