@@ -95,7 +95,11 @@ struct TDims {
     int B;    // batch size (multiple of 16, <= MAXB)
     int NB;   // workgroups of the per-board kernels = statistic partials per layer (<= 256)
     int S;    // workgroups that share a board (4 up to 64 boards, 2 up to 128, else 1): position tiles / taps are dealt out among them
+    int NRB;  // row blocks of the dense kernels: 1 = a workgroup sees ALL rows of its 16 columns (batch <= 128); above, the rows are split
+              // into NRB blocks of RB so that the whole chip works, and the batch statistics go through per-block partials (k_fc_fin, k_bn1d_bwd_fin)
+    int RB;   // rows per row block (multiple of 16)
 };
+#define NRBMAX 8
 
 struct TPtr {
     PSet p, m;
@@ -107,7 +111,10 @@ struct TPtr {
     float *y1, *h1, *mu1, *iv1, *y2, *h2, *mu2, *iv2, *dlog, *losspart;
     float *dz2, *dz1, *dy[4];
     double *bpart[3];   // backward sums of bn1..bn3: [NB][64] (sum dy, sum dy xhat per channel)
-    double *colsum;     // backward sums of bn4 per fc1 input column: [FIN][2]
+    double *colsum;     // backward sums of bn4 per fc1 input column and row block: [NRB][FIN][2]
+    double *fstat[2];   // row-split dense forward: (n, mean, M2) of y per (row block, column): [NRBMAX][N][3]
+    double *bstat[2];   // row-split BatchNorm1d backward: (sum dy, sum dy xhat, sum xhat) per (row block, column): [NRBMAX][N][3]
+    float *hwpart;      // row-split heads backward: the row block's share of d Wh [NRBMAX][NHP][F2], then of d bh [NRBMAX][NHP]
     float *gw[4];       // weight-gradient partials [NB][9*32*32 + 32] (conv1: [NB][9*32 + 32]): weights then bias
 };
 
@@ -162,7 +169,8 @@ AZ_D void bsum_walk(const TDims &d, const TPtr &q, int l, double &S1, double &S2
     const int t = threadIdx.x, ch = t & 31, grp = t >> 5;
     S1 = 0.0; S2 = 0.0;
     if (l == 3) {
-        for (int p = grp; p < d.P4; p += 8) { S1 += q.colsum[2 * (p * 32 + ch)]; S2 += q.colsum[2 * (p * 32 + ch) + 1]; }
+        for (int rb = 0; rb < d.NRB; ++rb)  // row blocks in order, positions dealt over the groups: a fixed summation order
+            for (int p = grp; p < d.P4; p += 8) { S1 += q.colsum[2 * ((size_t)rb * d.FIN + p * 32 + ch)]; S2 += q.colsum[2 * ((size_t)rb * d.FIN + p * 32 + ch) + 1]; }
     } else {
 #pragma unroll 8
         for (int p = grp; p < d.NB; p += 8) { S1 += q.bpart[l][(size_t)p * 64 + ch]; S2 += q.bpart[l][(size_t)p * 64 + 32 + ch]; }
@@ -586,25 +594,28 @@ AZ_D void reduce_waves(f32x4 (&acc)[RTM], float *red, int B, int RT, int wave, i
 // ---------------------------------------------------------------------------------------------------------------- dense forward
 // y = A W^T + b for 16 columns n0.. and all rows, column statistics, BatchNorm1d (train), ReLU, dropout.
 // layer 1: A = relu(bn4(c4)) formed on load (channel = k & 31), layer 2: A = h1.
-template <int RTM, int NW, int PF>
+// SPLIT: the workgroup (blockIdx.x, blockIdx.y) owns 16 columns and row block blockIdx.y (RTM * 16 rows): it writes y and the
+// (n, mean, M2) partial of its rows per column; k_fc_fin combines the partials of a column in row-block order and forms h.
+template <int RTM, int NW, int PF, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void k_fc_fwd(TDims d, TPtr q, int layer) {
     extern __shared__ __align__(16) float lds[];
-    const int B = d.B, RT = B / 16;
+    const int rb = SPLIT ? blockIdx.y : 0, r0 = rb * RTM * 16;
+    const int B = SPLIT ? min(d.B - r0, RTM * 16) : d.B, RT = B / 16;
     float *red = lds, *s_scale = red + NW * B * 16, *s_shift = s_scale + 32, *s_mean = s_shift + 32, *s_inv = s_mean + 32;
     double *scr = (double *)(s_inv + 32);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
     const int N = layer == 1 ? d.F1 : d.F2, K = layer == 1 ? d.FIN : d.F1, n0 = blockIdx.x * 16;
-    const float *A = layer == 1 ? q.c[3] : q.h1, *W = layer == 1 ? q.p.w1 : q.p.w2;
-    if (blockIdx.x == 0) TBEG(3 + layer);
+    const float *A = (layer == 1 ? q.c[3] : q.h1) + (size_t)r0 * K, *W = layer == 1 ? q.p.w1 : q.p.w2;
+    if (blockIdx.x == 0 && rb == 0) TBEG(3 + layer);
     const Hyper hp = *q.hp;
     TSTAMP(2, 0);
     const bool act = t < 256;
     const int col = t & 15, rg = (t >> 4) & 15, n = n0 + col;
     // what the epilogue needs from memory goes out now, under the K loop
     const float bias = (layer == 1 ? q.p.b1 : q.p.b2)[n];
-    const float g_ = (layer == 1 ? q.p.g1 : q.p.g2)[n], b_ = (layer == 1 ? q.p.be1 : q.p.be2)[n];
+    float g_ = 0.f, b_ = 0.f, rm_old = 0.f, rv_old = 0.f;
     float *rm = layer == 1 ? q.rm1 : q.rm2, *rv = layer == 1 ? q.rv1 : q.rv2;
-    const float rm_old = rm[n], rv_old = rv[n];
+    if (!SPLIT) { g_ = (layer == 1 ? q.p.g1 : q.p.g2)[n]; b_ = (layer == 1 ? q.p.be1 : q.p.be2)[n]; rm_old = rm[n]; rv_old = rv[n]; }
     const int chunk = ((K / 16 + NW - 1) / NW) * 16, kbeg = wave * chunk, kend = min(K, kbeg + chunk);
     f32x4 acc[RTM];
 #pragma unroll
@@ -638,12 +649,22 @@ __global__ __launch_bounds__(NW * 64) void k_fc_fwd(TDims d, TPtr q, int layer) 
     double M2 = 0.0;
 #pragma unroll
     for (int g = 0; g < 16; ++g) M2 += scr[g * 16 + col];
+    float *y = layer == 1 ? q.y1 : q.y2, *h = layer == 1 ? q.h1 : q.h2;
+    if (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < RTM; ++i)
+            if (i < RT) y[(size_t)(r0 + rg + 16 * i) * N + n] = v[i];
+        if (rg == 0) {
+            double *fs = q.fstat[layer - 1] + ((size_t)rb * N + n) * 3;
+            fs[0] = (double)B; fs[1] = mean; fs[2] = M2;
+        }
+        return;
+    }
     const double var = M2 / B;
 #ifdef AZ_TPROBE
     if (blockIdx.x == 0 && t == 0) az_tprobe[(3 + layer) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
 #endif
     const float inv = (float)(1.0 / sqrt(var + BN_EPS)), mu = (float)mean;
-    float *y = layer == 1 ? q.y1 : q.y2, *h = layer == 1 ? q.h1 : q.h2;
 #pragma unroll
     for (int i = 0; i < RTM; ++i)
         if (i < RT) {
@@ -664,6 +685,44 @@ __global__ __launch_bounds__(NW * 64) void k_fc_fwd(TDims d, TPtr q, int layer) 
 #ifdef AZ_TPROBE
     if (blockIdx.x == 0 && t == 0) az_tprobe[(3 + layer) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// second stage of the row-split dense forward: workgroup (16 columns, row block).  Every workgroup combines the row blocks' partials of
+// its columns in block order (Chan's merge: a fixed order, the same bits in every run), then y -> h = dropout(relu(bn(y))) for its
+// rows; row block 0 also writes the batch statistics and the running statistics.
+__global__ __launch_bounds__(TPB) void k_fc_fin(TDims d, TPtr q, int layer) {
+    const int t = threadIdx.x, col = t & 15, rg = t >> 4, rb = blockIdx.y, r0 = rb * d.RB, Bl = min(d.B - r0, d.RB);
+    const int N = layer == 1 ? d.F1 : d.F2, n = blockIdx.x * 16 + col;
+    const Hyper hp = *q.hp;
+    const float g_ = (layer == 1 ? q.p.g1 : q.p.g2)[n], b_ = (layer == 1 ? q.p.be1 : q.p.be2)[n];
+    const float *y = layer == 1 ? q.y1 : q.y2;
+    float *h = layer == 1 ? q.h1 : q.h2;
+    float yv[NRBMAX * 4 / 4 * 2];  // <= 128 rows per block / 16 row groups = 8 values
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (rg + 16 * i < Bl) yv[i] = y[(size_t)(r0 + rg + 16 * i) * N + n];
+    double cn = 0.0, mean = 0.0, M2 = 0.0;
+    for (int b = 0; b < d.NRB; ++b) {
+        const double *fs = q.fstat[layer - 1] + ((size_t)b * N + n) * 3;
+        if (b == 0) { cn = fs[0]; mean = fs[1]; M2 = fs[2]; } else chan_merge(cn, mean, M2, fs[0], fs[1], fs[2]);
+    }
+    const float inv = (float)(1.0 / sqrt(M2 / cn + BN_EPS)), mu = (float)mean;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (rg + 16 * i < Bl) {
+            const int r = r0 + rg + 16 * i;
+            const float xh = (yv[i] - mu) * inv;
+            float hh = fmaxf(fmaf(g_, xh, b_), 0.f);
+            hh *= dropout_scale(hp, layer, (unsigned)(r * N + n));
+            h[(size_t)r * N + n] = hh;
+        }
+    if (rb == 0 && rg == 0) {
+        float *rm = layer == 1 ? q.rm1 : q.rm2, *rv = layer == 1 ? q.rv1 : q.rv2;
+        (layer == 1 ? q.mu1 : q.mu2)[n] = mu;
+        (layer == 1 ? q.iv1 : q.iv2)[n] = inv;
+        rm[n] = (float)((1.0 - BN_MOM) * rm[n] + BN_MOM * mean);
+        rv[n] = (float)((1.0 - BN_MOM) * rv[n] + BN_MOM * (M2 / (cn > 1.0 ? cn - 1.0 : 1.0)));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- heads forward + loss
@@ -766,18 +825,20 @@ __global__ __launch_bounds__(NW * 64) void k_heads_fwd(TDims d, TPtr q) {
 // of the first 256 threads owns rows rg, rg + 16, ...: mask (h > 0 <=> ReLU passed and the unit was kept), batch sums,
 // dz = g inv (dy - mean(dy) - xhat mean(dy xhat)), then the SGD update of the BatchNorm affine pair and of the dense bias (its gradient,
 // sum dz, is zero up to rounding).  Every thread of the workgroup must call (barriers inside).
-template <int RTM>
-AZ_D void bn1d_bwd(const TDims &d, const TPtr &q, const Hyper &hp, int layer, int n0, const float *dh, double *scr /* [16][16] */) {
-    const int B = d.B, RT = B / 16, t = threadIdx.x, col = t & 15, rg = (t >> 4) & 15, n = n0 + col, N = layer == 1 ? d.F1 : d.F2;
+// SPLIT (row-split path): the workgroup holds rows r0 .. r0 + Bl only.  It masks dh -> dy (stored where dz will be), and leaves the three
+// sums of its rows per column -- sum dy, sum dy xhat, sum xhat -- in bstat; k_bn1d_bwd_fin combines them in row-block order and forms dz.
+template <int RTM, bool SPLIT = false>
+AZ_D void bn1d_bwd(const TDims &d, const TPtr &q, const Hyper &hp, int layer, int n0, const float *dh, double *scr /* [3][16][16] */, int r0 = 0, int Bl = 0) {
+    const int B = SPLIT ? Bl : d.B, RT = B / 16, t = threadIdx.x, col = t & 15, rg = (t >> 4) & 15, n = n0 + col, N = layer == 1 ? d.F1 : d.F2;
     const bool act = t < 256;
-    const float *y = layer == 1 ? q.y1 : q.y2, *h = layer == 1 ? q.h1 : q.h2;
-    float *dz = layer == 1 ? q.dz1 : q.dz2;
+    const float *y = (layer == 1 ? q.y1 : q.y2) + (size_t)r0 * N, *h = (layer == 1 ? q.h1 : q.h2) + (size_t)r0 * N;
+    float *dz = (layer == 1 ? q.dz1 : q.dz2) + (size_t)r0 * N;
     const float mu = (layer == 1 ? q.mu1 : q.mu2)[n], iv = (layer == 1 ? q.iv1 : q.iv2)[n];
     float *gam = layer == 1 ? q.p.g1 : q.p.g2, *bet = layer == 1 ? q.p.be1 : q.p.be2, *bia = layer == 1 ? q.p.b1 : q.p.b2;
     float *mgam = layer == 1 ? q.m.g1 : q.m.g2, *mbet = layer == 1 ? q.m.be1 : q.m.be2, *mbia = layer == 1 ? q.m.b1 : q.m.b2;
     const float keep = hp.drop_p > 0.0f ? 1.0f / (1.0f - hp.drop_p) : 1.0f;
     float dyv[RTM], xh[RTM];
-    double s1 = 0.0, s2 = 0.0;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (act) {
         float hv[RTM], yv[RTM];
 #pragma unroll
@@ -789,13 +850,26 @@ AZ_D void bn1d_bwd(const TDims &d, const TPtr &q, const Hyper &hp, int layer, in
                 dyv[i] = hv[i] > 0.0f ? dh[(rg + 16 * i) * 16 + col] * keep : 0.0f;
                 xh[i] = (yv[i] - mu) * iv;
                 s1 += dyv[i]; s2 += (double)dyv[i] * (double)xh[i];
+                if (SPLIT) { s3 += xh[i]; dz[(size_t)(rg + 16 * i) * N + n] = dyv[i]; }
             }
         scr[rg * 16 + col] = s1; scr[256 + rg * 16 + col] = s2;
+        if (SPLIT) scr[512 + rg * 16 + col] = s3;
     }
     __syncthreads();
     double S1 = 0.0, S2 = 0.0;
 #pragma unroll
     for (int g = 0; g < 16; ++g) { S1 += scr[g * 16 + col]; S2 += scr[256 + g * 16 + col]; }
+    if (SPLIT) {
+        if (act && rg == 0) {
+            double S3 = 0.0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) S3 += scr[512 + g * 16 + col];
+            double *bs = q.bstat[layer - 1] + ((size_t)(r0 / d.RB) * N + n) * 3;
+            bs[0] = S1; bs[1] = S2; bs[2] = S3;
+        }
+        __syncthreads();
+        return;
+    }
     __syncthreads();
     if (act) {
         const float k = gam[n] * iv, m1 = (float)(S1 / B), m2 = (float)(S2 / B);
@@ -821,17 +895,69 @@ AZ_D void bn1d_bwd(const TDims &d, const TPtr &q, const Hyper &hp, int layer, in
     __syncthreads();
 }
 
+// second stage of the row-split BatchNorm1d backward: workgroup (16 columns, row block).  The row blocks' sums are added in block
+// order; dz = g inv (dy - mean(dy) - xhat mean(dy xhat)) in place over the dy the first stage left; row block 0 updates the affine
+// pair and the dense bias.  The bias gradient sum dz is zero in exact arithmetic (BatchNorm removes the batch mean); what float32
+// leaves of it is the rounding of the two means, k ((S1 - B m1) - m2 Sx) with the ROUNDED m1, m2 -- computed here from the sums
+// instead of a third pass over the rows.
+__global__ __launch_bounds__(TPB) void k_bn1d_bwd_fin(TDims d, TPtr q, int layer) {
+    const int t = threadIdx.x, col = t & 15, rg = t >> 4, rb = blockIdx.y, r0 = rb * d.RB, Bl = min(d.B - r0, d.RB);
+    const int N = layer == 1 ? d.F1 : d.F2, n = blockIdx.x * 16 + col;
+    const Hyper hp = *q.hp;
+    const float *y = layer == 1 ? q.y1 : q.y2;
+    float *dz = layer == 1 ? q.dz1 : q.dz2;
+    float *gam = layer == 1 ? q.p.g1 : q.p.g2, *bet = layer == 1 ? q.p.be1 : q.p.be2, *bia = layer == 1 ? q.p.b1 : q.p.b2;
+    float *mgam = layer == 1 ? q.m.g1 : q.m.g2, *mbet = layer == 1 ? q.m.be1 : q.m.be2, *mbia = layer == 1 ? q.m.b1 : q.m.b2;
+    const float mu = (layer == 1 ? q.mu1 : q.mu2)[n], iv = (layer == 1 ? q.iv1 : q.iv2)[n], gv = gam[n];
+    float dyv[8], yv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (rg + 16 * i < Bl) { dyv[i] = dz[(size_t)(r0 + rg + 16 * i) * N + n]; yv[i] = y[(size_t)(r0 + rg + 16 * i) * N + n]; }
+    double S1 = 0.0, S2 = 0.0, S3 = 0.0;
+    for (int b = 0; b < d.NRB; ++b) {
+        const double *bs = q.bstat[layer - 1] + ((size_t)b * N + n) * 3;
+        S1 += bs[0]; S2 += bs[1]; S3 += bs[2];
+    }
+    const float k = gv * iv, m1 = (float)(S1 / d.B), m2 = (float)(S2 / d.B);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (rg + 16 * i < Bl) dz[(size_t)(r0 + rg + 16 * i) * N + n] = k * ((dyv[i] - m1) - ((yv[i] - mu) * iv) * m2);
+    if (rb == 0 && rg == 0) {
+        const double SD = (double)k * ((S1 - (double)d.B * (double)m1) - (double)m2 * S3);
+        sgd(gam + n, mgam + n, (float)S2, hp);
+        sgd(bet + n, mbet + n, (float)S1, hp);
+        sgd(bia + n, mbia + n, (float)SD, hp);
+    }
+    if (layer == 2) {  // the heads: shares of d Wh / d bh that k_heads_bwd's row blocks left, added in block order; row block rb of this
+        const int F2 = d.F2, NHP = d.NHP;  // launch takes the rows a = rb (mod NRB) of its 16 columns
+        for (int a = rg; a < d.NH; a += 16) {
+            if (a % d.NRB != rb) continue;
+            float g = 0.f;
+            for (int b = 0; b < d.NRB; ++b) g += q.hwpart[((size_t)b * NHP + a) * F2 + n];
+            sgd(q.p.wh + (size_t)a * F2 + n, q.m.wh + (size_t)a * F2 + n, g, hp);
+        }
+        if (blockIdx.x == 0 && rb == 0 && t < d.NH) {
+            float g = 0.f;
+            for (int b = 0; b < d.NRB; ++b) g += q.hwpart[(size_t)NRBMAX * NHP * F2 + (size_t)b * NHP + t];
+            sgd(q.p.bh + t, q.m.bh + t, g, hp);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- heads backward
 // 16 columns j0.. of fc2's output: d h2 = dlog Wh (K = NHP), fc_bn2 backward -> dz2, then the heads' weight gradient for the
 // same columns (dWh[a][j] = sum_b dlog[b][a] h2[b][j]) and its update: this workgroup is the only reader and writer of Wh[:, j0..]
-template <int RTM, int NT>
+// SPLIT: workgroup (16 columns, row block): d h2 and the first stage of fc_bn2's backward for its rows; the heads' weight gradient (a
+// sum over ALL rows) is taken by the workgroups of row block 0.
+template <int RTM, int NT, bool SPLIT>
 __global__ __launch_bounds__(TPB) void k_heads_bwd(TDims d, TPtr q) {
     extern __shared__ __align__(16) float lds[];
-    const int B = d.B, RT = B / 16, NHP = NT * 16, F2 = d.F2;
+    const int rb = SPLIT ? blockIdx.y : 0, r0 = rb * RTM * 16;
+    const int B = d.B, Bl = SPLIT ? min(B - r0, RTM * 16) : B, RT = Bl / 16, NHP = NT * 16, F2 = d.F2;
     float *dh = lds;
-    double *scr = (double *)(dh + B * 16);
+    double *scr = (double *)(dh + Bl * 16);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, j0 = blockIdx.x * 16;
-    if (blockIdx.x == 1) TBEG(7);
+    if (blockIdx.x == 1 && rb == 0) TBEG(7);
     const Hyper hp = *q.hp;
     float wb[NT][4];  // Wh[a][j0 + n16] for the lane's rows a = 16 nt + 4 kq + i: loaded once, used by every row tile
 #pragma unroll
@@ -841,7 +967,7 @@ __global__ __launch_bounds__(TPB) void k_heads_bwd(TDims d, TPtr q) {
     for (int rt = wave; rt < RT; rt += 4) {
         float4 af[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) af[nt] = *(const float4 *)(q.dlog + (size_t)(16 * rt + n16) * NHP + 16 * nt + 4 * kq);
+        for (int nt = 0; nt < NT; ++nt) af[nt] = *(const float4 *)(q.dlog + (size_t)(r0 + 16 * rt + n16) * NHP + 16 * nt + 4 * kq);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -851,7 +977,44 @@ __global__ __launch_bounds__(TPB) void k_heads_bwd(TDims d, TPtr q) {
         for (int r = 0; r < 4; ++r) dh[(16 * rt + 4 * kq + r) * 16 + n16] = acc[r];
     }
     __syncthreads();
-    bn1d_bwd<RTM>(d, q, hp, 2, j0, dh, scr);
+    bn1d_bwd<RTM, SPLIT>(d, q, hp, 2, j0, dh, scr, r0, Bl);
+    if (SPLIT) {
+        // the heads' weight gradient is a sum over ALL rows: this workgroup adds up its own rows (d Wh[a][j0..] over r0 .. r0 + Bl) and
+        // leaves the share in hwpart[rb]; k_bn1d_bwd_fin (layer 2, row block 0) adds the shares in block order and updates Wh, bh
+        float *wp = q.hwpart + (size_t)rb * NHP * F2;
+        for (int at = wave; at < NT; at += 4) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int b0 = 0; b0 < Bl; b0 += 32) {
+                float a[8], h[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    if (b0 + 4 * p < Bl) { a[p] = q.dlog[(size_t)(r0 + b0 + 4 * p + kq) * NHP + 16 * at + n16]; h[p] = q.h2[(size_t)(r0 + b0 + 4 * p + kq) * F2 + j0 + n16]; }
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    if (b0 + 4 * p < Bl) acc = MFMA(a[p], h[p], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wp[(size_t)(16 * at + 4 * kq + r) * F2 + j0 + n16] = acc[r];
+        }
+        if (blockIdx.x == 0) {  // d bh: column sums of dlog over this block's rows, 16 row groups then LDS
+            float *bp = q.hwpart + (size_t)NRBMAX * NHP * F2 + (size_t)rb * NHP;
+            const int col = t & 15, rg = t >> 4;
+            for (int at = 0; at < NT; ++at) {
+                double g = 0.0;
+                for (int b = rg; b < Bl; b += 16) g += q.dlog[(size_t)(r0 + b) * NHP + 16 * at + col];
+                scr[rg * 16 + col] = g;
+                __syncthreads();
+                if (rg == 0) {
+                    double G = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) G += scr[k * 16 + col];
+                    bp[16 * at + col] = (float)G;
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
     for (int at = wave; at < NT; at += 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int b0 = 0; b0 < B; b0 += 32) {  // eight steps of 4 rows per trip: all loads first
@@ -876,27 +1039,28 @@ __global__ __launch_bounds__(TPB) void k_heads_bwd(TDims d, TPtr q) {
             for (int b = 0; b < B; ++b) g += q.dlog[(size_t)b * NHP + a];
             sgd(q.p.bh + a, q.m.bh + a, (float)g, hp);
         }
-    if (blockIdx.x == 1) TEND(7);
+    if (blockIdx.x == 1 && rb == 0) TEND(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dense data gradient
 // d h1 = dz2 W2 (the not yet updated W2) for 16 columns of fc1's output and all rows, then fc_bn1 backward
-template <int RTM, int NW, int PF>
+template <int RTM, int NW, int PF, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void k_fc_dgrad(TDims d, TPtr q) {
     extern __shared__ __align__(16) float lds[];
+    const int rb = SPLIT ? blockIdx.y : 0, r0 = rb * RTM * 16, Bl = SPLIT ? min(d.B - r0, RTM * 16) : d.B;
     float *red = lds;
-    double *scr = (double *)(red + NW * d.B * 16 + 4 * 32);
-    if (blockIdx.x == 0) TBEG(8);
+    double *scr = (double *)(red + NW * Bl * 16 + 4 * 32);
+    if (blockIdx.x == 0 && rb == 0) TBEG(8);
     const Hyper hp = *q.hp;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, RT = d.B / 16, J = d.F2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, RT = Bl / 16, J = d.F2;
     const int chunk = ((J / 16 + NW - 1) / NW) * 16, jbeg = wave * chunk, jend = min(J, jbeg + chunk);
     f32x4 acc[RTM];
 #pragma unroll
     for (int i = 0; i < RTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    nn_kloop<RTM, PF>(acc, q.dz2, J, q.p.w2 + blockIdx.x * 16, d.F1, RT, jbeg, jend, n16, kq, [] {});
-    reduce_waves<RTM, NW>(acc, red, d.B, RT, wave, n16, kq);
-    bn1d_bwd<RTM>(d, q, hp, 1, blockIdx.x * 16, red, scr);
-    if (blockIdx.x == 0) TEND(8);
+    nn_kloop<RTM, PF>(acc, q.dz2 + (size_t)r0 * J, J, q.p.w2 + blockIdx.x * 16, d.F1, RT, jbeg, jend, n16, kq, [] {});
+    reduce_waves<RTM, NW>(acc, red, Bl, RT, wave, n16, kq);
+    bn1d_bwd<RTM, SPLIT>(d, q, hp, 1, blockIdx.x * 16, red, scr, r0, Bl);
+    if (blockIdx.x == 0 && rb == 0) TEND(8);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dense weight gradient
@@ -958,37 +1122,109 @@ AZ_D void fc_wgrad_tile(const TDims &d, const TPtr &q, const Hyper &hp, int laye
 
 static inline int fc_wgrad_blocks(int N, int K, int NW) { return ((N / 32) * (K / 32) + NW - 1) / NW; }
 
+// The same tile with its K (the batch rows) split over FOUR waves: wave (tile, ks) multiplies rows [ks B/4, (ks+1) B/4), the four
+// partial tiles meet in LDS (part[wave][32 x 32]) and wave ks = 0 adds them in order and updates.  At batch 512 one wave walking all
+// rows is sixteen dependent trips of eight MFMA steps; a quarter each is four.  Every wave of the workgroup must call (one barrier).
+AZ_D void fc_wgrad_tile_ks(const TDims &d, const TPtr &q, const Hyper &hp, int layer, int tile, int ks, float *part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n16 = lane & 15, kq = lane >> 4;
+    const int N = layer == 1 ? d.F1 : d.F2, K = layer == 1 ? d.FIN : d.F1, TK = K / 32;
+    const bool live = tile < (N / 32) * TK;
+    const int j0 = 32 * (tile / TK), k0 = 32 * (tile % TK);
+    const float *dZ = layer == 1 ? q.dz1 : q.dz2, *X = layer == 1 ? q.c[3] : q.h1;
+    float *W = layer == 1 ? q.p.w1 : q.p.w2, *M = layer == 1 ? q.m.w1 : q.m.w2;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float wo[2][2][4], mo[2][2][4];
+    if (live && ks == 0)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t idx = (size_t)(j0 + 16 * mt + 4 * kq + r) * K + k0 + 16 * nt + n16;
+                    wo[mt][nt][r] = W[idx]; mo[mt][nt][r] = M[idx];
+                }
+    if (live) {
+        const int per = ((d.B / 4 + 3) / 4) * 4, bbeg = ks * per, bend = min(d.B, bbeg + per);
+        for (int b0 = bbeg; b0 < bend; b0 += 32) {
+            float a0[8], a1[8], x0[8], x1[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (b0 + 4 * p < bend) {
+                    const float *zp = dZ + (size_t)(b0 + 4 * p + kq) * N + j0 + n16, *xp = X + (size_t)(b0 + 4 * p + kq) * K + k0 + n16;
+                    a0[p] = zp[0]; a1[p] = zp[16]; x0[p] = xp[0]; x1[p] = xp[16];
+                }
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (b0 + 4 * p < bend) {
+                    acc[0][0] = MFMA(a0[p], x0[p], acc[0][0]); acc[0][1] = MFMA(a0[p], x1[p], acc[0][1]);
+                    acc[1][0] = MFMA(a1[p], x0[p], acc[1][0]); acc[1][1] = MFMA(a1[p], x1[p], acc[1][1]);
+                }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[(size_t)wave * 1024 + ((mt * 2 + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    if (!live || ks != 0) return;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = ((mt * 2 + nt) * 4 + r) * 64 + lane;
+                const float g = ((part[(size_t)wave * 1024 + o] + part[(size_t)(wave + 1) * 1024 + o]) + part[(size_t)(wave + 2) * 1024 + o]) + part[(size_t)(wave + 3) * 1024 + o];
+                const size_t idx = (size_t)(j0 + 16 * mt + 4 * kq + r) * K + k0 + 16 * nt + n16;
+                const float gg = fmaf(hp.wd, wo[mt][nt][r], g);
+                const float mm = fmaf(hp.momentum, mo[mt][nt][r], gg);
+                M[idx] = mm;
+                W[idx] = fmaf(-hp.lr, mm, wo[mt][nt][r]);
+            }
+}
+
 // k_mix1: [0, nw) fc2 weight gradient + update (reads dz2, h1; writes W2 -- the data gradient through W2 ran in the launch before) |
 //         [nw, nw + FIN/16) d a4 = dz1 W1 for 16 input columns (old W1), ReLU mask of a4, dy4 and the per-column sums bn4's backward needs
-template <int RTM, int NW, int PF>
+// SPLIT: the d a4 part has a workgroup per (16 input columns, row block): block index nw + cb * NRB + rb; its column sums go to the
+// row block's slice of colsum (the consumers add the slices in order).
+template <int RTM, int NW, int PF, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void k_mix1(TDims d, TPtr q, int nw) {
     extern __shared__ __align__(16) float lds[];
     const Hyper hp = *q.hp;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4;
-    if ((int)blockIdx.x < nw) {
-        if (blockIdx.x == 0) TBEG(9);
-        fc_wgrad_tile<(NW >= 16 ? 4 : 8)>(d, q, hp, 2, blockIdx.x * NW + wave, nullptr, nullptr);
-        if (blockIdx.x == 0) TEND(9);
+    // SPLIT: the data-gradient workgroups come FIRST in the grid (they are the longer chain: K = F1), the weight-gradient tiles fill in behind
+    const int ndg = SPLIT ? (int)gridDim.x - nw : 0, wid = SPLIT ? (int)blockIdx.x - ndg : (int)blockIdx.x;
+    if (SPLIT ? wid >= 0 : wid < nw) {
+        if (wid == 0) TBEG(9);
+        if (SPLIT) fc_wgrad_tile_ks(d, q, hp, 2, wid * (NW / 4) + (wave >> 2), wave & 3, lds);
+        else fc_wgrad_tile<(NW >= 16 ? 4 : 8)>(d, q, hp, 2, wid * NW + wave, nullptr, nullptr);
+        if (wid == 0) TEND(9);
         return;
     }
-    if ((int)blockIdx.x == nw) TBEG(10);
-    const int B = d.B, RT = B / 16, FIN = d.FIN, J = d.F1, k0 = ((int)blockIdx.x - nw) * 16;
+    if ((int)blockIdx.x == (SPLIT ? 0 : nw)) TBEG(10);
+    const int id = SPLIT ? (int)blockIdx.x : (int)blockIdx.x - nw, rb = SPLIT ? id % d.NRB : 0, r0 = rb * RTM * 16;
+    const int B = SPLIT ? min(d.B - r0, RTM * 16) : d.B, RT = B / 16, FIN = d.FIN, J = d.F1, k0 = (SPLIT ? id / d.NRB : id) * 16;
     float *red = lds, *s_scale = red + NW * B * 16, *s_shift = s_scale + 32, *s_mean = s_shift + 32, *s_inv = s_mean + 32;
     double *scr = (double *)(s_inv + 32);
     const int chunk = ((J / 16 + NW - 1) / NW) * 16, jbeg = wave * chunk, jend = min(J, jbeg + chunk);
     f32x4 acc[RTM];
 #pragma unroll
     for (int i = 0; i < RTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    nn_kloop<RTM, PF>(acc, q.dz1, J, q.p.w1 + k0, FIN, RT, jbeg, jend, n16, kq,
+    nn_kloop<RTM, PF>(acc, q.dz1 + (size_t)r0 * J, J, q.p.w1 + k0, FIN, RT, jbeg, jend, n16, kq,
                       [&] { bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr); });  // the statistics are combined under the first loads
     reduce_waves<RTM, NW>(acc, red, B, RT, wave, n16, kq);
     const int col = t & 15, rg = (t >> 4) & 15, k = k0 + col, ch = k & 31;
     double s1 = 0.0, s2 = 0.0;
     if (t < 256) {
         for (int r = rg; r < B; r += 16) {
-            const float cv = q.c[3][(size_t)r * FIN + k];
+            const float cv = q.c[3][(size_t)(r0 + r) * FIN + k];
             const float v = fmaf(cv, s_scale[ch], s_shift[ch]) > 0.0f ? red[r * 16 + col] : 0.0f;
-            q.dy[3][(size_t)r * FIN + k] = v;
+            q.dy[3][(size_t)(r0 + r) * FIN + k] = v;
             s1 += v; s2 += (double)v * (double)((cv - s_mean[ch]) * s_inv[ch]);
         }
         scr[rg * 16 + col] = s1; scr[256 + rg * 16 + col] = s2;
@@ -997,9 +1233,9 @@ __global__ __launch_bounds__(NW * 64) void k_mix1(TDims d, TPtr q, int nw) {
     if (t < 16) {
         double S1 = 0.0, S2 = 0.0;
         for (int g = 0; g < 16; ++g) { S1 += scr[g * 16 + col]; S2 += scr[256 + g * 16 + col]; }
-        q.colsum[2 * k] = S1; q.colsum[2 * k + 1] = S2;
+        q.colsum[2 * ((size_t)rb * FIN + k)] = S1; q.colsum[2 * ((size_t)rb * FIN + k) + 1] = S2;
     }
-    if ((int)blockIdx.x == nw) TEND(10);
+    if ((int)blockIdx.x == (SPLIT ? 0 : nw)) TEND(10);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- conv backward
@@ -1291,17 +1527,15 @@ __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
     if (blockIdx.x == gridDim.x - 1) TBEG(17);
     const Hyper hp = *q.hp;
     const int t = threadIdx.x;
-    if (blockIdx.x == gridDim.x - 1) {
-        for (int l = 0; l < 4; ++l) {
-            bn2d_combine(q.fpart[l], d.NB, s_mean, s_var, scr);
-            if (t < 32) {
-                const double n = (double)d.B * plane_of(d, l);
-                q.rm[l][t] = (float)((1.0 - BN_MOM) * q.rm[l][t] + BN_MOM * s_mean[t]);
-                q.rv[l][t] = (float)((1.0 - BN_MOM) * q.rv[l][t] + BN_MOM * ((double)s_var[t] * n / (n > 1.0 ? n - 1.0 : 1.0)));
-            }
-            __syncthreads();
+    if (blockIdx.x >= gridDim.x - 4) {  // the last four workgroups: one BatchNorm2d layer's running statistics each (a walk over NB partials)
+        const int l = (int)(gridDim.x - 1 - blockIdx.x);
+        bn2d_combine(q.fpart[l], d.NB, s_mean, s_var, scr);
+        if (t < 32) {
+            const double n = (double)d.B * plane_of(d, l);
+            q.rm[l][t] = (float)((1.0 - BN_MOM) * q.rm[l][t] + BN_MOM * s_mean[t]);
+            q.rv[l][t] = (float)((1.0 - BN_MOM) * q.rv[l][t] + BN_MOM * ((double)s_var[t] * n / (n > 1.0 ? n - 1.0 : 1.0)));
         }
-        if (t == 0) {
+        if (l == 0 && t == 64) {  // (another wave than the one finishing the statistics) the step's losses, then the counters of the next step
             double a0 = 0.0, a1 = 0.0;
             for (int i = 0; i < d.B / 16; ++i) { a0 += q.losspart[2 * i]; a1 += q.losspart[2 * i + 1]; }
             q.loss_pi[hp.loss_off] = (float)(a0 / d.B); q.loss_v[hp.loss_off] = (float)(a1 / d.B);
@@ -1312,45 +1546,72 @@ __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
         }
         return;
     }
-    const int e = blockIdx.x * TPB + t;
-    if (e >= UPD_ALL) return;
+    // 64 elements per workgroup; the four waves each sum a quarter of the element's partials (wave w: partials [w NP/4, (w+1) NP/4), sixteen
+    // loads per trip), the quarters meet in LDS and are added in order -- a fixed summation order, a quarter of the dependent trips
+    const int lane = t & 63, part = t >> 6, e = blockIdx.x * 64 + lane;
+    double *qs = scr;  // [4][64]
     TSTAMP(4, 0);
+    double acc = 0.0;
+    int kind = -1, l = 0, i = 0, c = 0;
+    bool gam = false;
     if (e < UPD_W) {
-        const int l = e < UPD_W1 ? 0 : 1 + (e - UPD_W1) / 9216, i = e < UPD_W1 ? e : (e - UPD_W1) % 9216, sz = l == 0 ? 9 * 32 + 32 : 9 * 32 * 32 + 32;
-        float g = 0.0f;
-        const float *gp = q.gw[l] + i;
+        kind = 0;
+        l = e < UPD_W1 ? 0 : 1 + (e - UPD_W1) / 9216; i = e < UPD_W1 ? e : (e - UPD_W1) % 9216;
+        const int sz = l == 0 ? 9 * 32 + 32 : 9 * 32 * 32 + 32;
         const int NP = l == 0 ? d.NB : d.NB / d.S;  // conv2..4: the S workgroups that share boards fill one partial together
-        for (int p0 = 0; p0 < NP; p0 += 16) {  // sixteen partials per trip: the loads go out together, the sum keeps its order
+        const int per = (NP + 3) / 4, pbeg = part * per, pend = min(NP, pbeg + per);
+        const float *gp = q.gw[l] + i;
+        float g = 0.0f;
+        for (int p0 = pbeg; p0 < pend; p0 += 16) {
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = p0 + u < NP ? gp[(size_t)(p0 + u) * sz] : 0.0f;
+            for (int u = 0; u < 16; ++u) v[u] = p0 + u < pend ? gp[(size_t)(p0 + u) * sz] : 0.0f;
 #pragma unroll
             for (int u = 0; u < 16; ++u) g += v[u];
         }
-        sgd(q.p.cw[l] + i, q.m.cw[l] + i, g, hp);
-        TSTAMP(4, 1);
-#ifdef AZ_TPROBE
-        if (blockIdx.x == 0 && t == 0) az_tprobe[16 * 16 + 15] = __builtin_amdgcn_s_memrealtime();
-#endif
+        acc = g;
     } else if (e < UPD_B) {
-        const int l = (e - UPD_W) >> 5, c = (e - UPD_W) & 31, sz = l == 0 ? 9 * 32 + 32 : 9 * 32 * 32 + 32;
-        float g = 0.0f;
+        kind = 1;
+        l = (e - UPD_W) >> 5; c = (e - UPD_W) & 31;
+        const int sz = l == 0 ? 9 * 32 + 32 : 9 * 32 * 32 + 32;
         const int NP = l == 0 ? d.NB : d.NB / d.S;
+        const int per = (NP + 3) / 4, pbeg = part * per, pend = min(NP, pbeg + per);
+        float g = 0.0f;
 #pragma unroll 8
-        for (int p = 0; p < NP; ++p) g += q.gw[l][(size_t)p * sz + sz - 32 + c];
-        sgd(q.p.cb[l] + c, q.m.cb[l] + c, g, hp);
-    } else {
-        const bool gam = e < UPD_G;
-        const int l = ((e - (gam ? UPD_B : UPD_G)) >> 5), c = e & 31;  // UPD_B and UPD_G are multiples of 32
+        for (int p = pbeg; p < pend; ++p) g += q.gw[l][(size_t)p * sz + sz - 32 + c];
+        acc = g;
+    } else if (e < UPD_ALL) {
+        kind = 2;
+        gam = e < UPD_G;
+        l = ((e - (gam ? UPD_B : UPD_G)) >> 5); c = e & 31;  // UPD_B and UPD_G are multiples of 32
         double S = 0.0;
-        if (l == 3) { for (int p = 0; p < d.P4; ++p) S += q.colsum[2 * (p * 32 + c) + (gam ? 1 : 0)]; }
-        else {
+        if (l == 3) {
+            const int per = (d.P4 + 3) / 4, pbeg = part * per, pend = min(d.P4, pbeg + per);
+            for (int rb = 0; rb < d.NRB; ++rb)
+                for (int p = pbeg; p < pend; ++p) S += q.colsum[2 * ((size_t)rb * d.FIN + p * 32 + c) + (gam ? 1 : 0)];
+        } else {
+            const int per = (d.NB + 3) / 4, pbeg = part * per, pend = min(d.NB, pbeg + per);
 #pragma unroll 8
-            for (int p = 0; p < d.NB; ++p) S += q.bpart[l][(size_t)p * 64 + (gam ? 32 : 0) + c];
+            for (int p = pbeg; p < pend; ++p) S += q.bpart[l][(size_t)p * 64 + (gam ? 32 : 0) + c];
         }
+        acc = S;
+    }
+    qs[part * 64 + lane] = acc;
+    __syncthreads();
+    if (part != 0 || kind < 0) return;
+    if (kind == 2) {
+        const double S = ((qs[lane] + qs[64 + lane]) + qs[128 + lane]) + qs[192 + lane];
         if (gam) sgd(q.p.bg[l] + c, q.m.bg[l] + c, (float)S, hp);
         else sgd(q.p.bb[l] + c, q.m.bb[l] + c, (float)S, hp);
+    } else {
+        const float g = (((float)qs[lane] + (float)qs[64 + lane]) + (float)qs[128 + lane]) + (float)qs[192 + lane];
+        if (kind == 0) sgd(q.p.cw[l] + i, q.m.cw[l] + i, g, hp);
+        else sgd(q.p.cb[l] + c, q.m.cb[l] + c, g, hp);
     }
+    TSTAMP(4, 1);
+#ifdef AZ_TPROBE
+    if (blockIdx.x == 0 && t == 0) az_tprobe[16 * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------- TicTacToeNet
@@ -1675,7 +1936,7 @@ extern "C" int az_trainer_create(int game, int H, int W, int max_batch, az_train
     d.P1 = d.CH * d.CW; d.H3 = d.CH - 2; d.W3 = d.CW - 2; d.P3 = d.H3 * d.W3; d.H4 = d.CH - 4; d.W4 = d.CW - 4; d.P4 = d.H4 * d.W4;
     d.FIN = 32 * d.P4; d.NH = d.A + 1; d.NHP = (d.NH + 15) / 16 * 16;
     AZ_REQUIRE(d.NHP == 16 || d.NHP == 48 || d.NHP == 80, AZ_EINVAL, "no heads kernel for %d outputs", d.NH);
-    d.B = max_batch; d.S = 1; d.NB = max_batch < 256 ? max_batch : 256;
+    d.B = max_batch; d.S = 1; d.NB = max_batch < 256 ? max_batch : 256; d.NRB = 1; d.RB = max_batch;
     az_trainer *t = new az_trainer();
     t->game = game; t->H = H; t->W = W; t->max_batch = max_batch; t->d = d;
     memset(&t->q, 0, sizeof t->q);
@@ -1701,7 +1962,9 @@ extern "C" int az_trainer_create(int game, int H, int W, int max_batch, az_train
     TA(x0, B * d.P1); TA(y1, B * d.F1); TA(h1, B * d.F1); TA(mu1, d.F1); TA(iv1, d.F1);
     TA(y2, B * d.F2); TA(h2, B * d.F2); TA(mu2, d.F2); TA(iv2, d.F2);
     TA(dlog, B * d.NHP); TA(losspart, (B / 16) * 2); TA(dz2, B * d.F2); TA(dz1, B * d.F1);
-    TA(colsum, (size_t)d.FIN * 2); TA(hp, 1);
+    TA(colsum, (size_t)NRBMAX * d.FIN * 2); TA(hp, 1);
+    TA(hwpart, (size_t)NRBMAX * d.NHP * (d.F2 + 1));
+    TA(fstat[0], (size_t)NRBMAX * d.F1 * 3); TA(fstat[1], (size_t)NRBMAX * d.F2 * 3); TA(bstat[0], (size_t)NRBMAX * d.F1 * 3); TA(bstat[1], (size_t)NRBMAX * d.F2 * 3);
 #undef TA
 #undef PA
     if (rc == AZ_OK && (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1794,7 +2057,7 @@ extern "C" int az_trainer_begin(az_trainer *t, float lr, float momentum, float w
     hipStream_t user = (hipStream_t)stream;
     AZ_TRY(t_enter(t, user));
     for (auto &m : t->momenta) AZ_HIP(hipMemsetAsync(m.first, 0, m.second * sizeof(float), t->stream));
-    Hyper h;
+    Hyper h{};
     h.lr = lr; h.momentum = momentum; h.wd = weight_decay; h.drop_p = dropout_p; h.seed = seed; h.step = 0; h.perm_off = 0; h.loss_off = 0;
     AZ_HIP(hipMemcpyAsync(t->q.hp, &h, sizeof h, hipMemcpyHostToDevice, t->stream));
     AZ_HIP(hipStreamSynchronize(t->stream));  // h lives on this frame
@@ -1811,12 +2074,14 @@ extern "C" int az_trainer_set_lr(az_trainer *t, float lr, void *stream) {
     return t_leave(t, user);
 }
 
-template <int RTM, int NW, int PF, int NT>
+template <int RTM, int NW, int PF, int NT, bool SPLIT>
 static int enqueue_step_t(az_trainer *t) {
     const TDims &d = t->d;
     const TPtr &q = t->q;
     hipStream_t st = t->stream;
-    const int fcl = fc_lds_bytes(NW, d.B), hbl = d.B * 16 * 4 + 512 * 8;
+    const int Bw = SPLIT ? RTM * 16 : d.B;  // rows a dense workgroup holds
+    const int fcl = fc_lds_bytes(NW, Bw), hbl = Bw * 16 * 4 + 768 * 8;
+    const unsigned NRB = SPLIT ? (unsigned)d.NRB : 1u;
 #define SETATTR(k, bytes) AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)))
     if (!t->attrs_set) {
         SETATTR(k_conv_fwd, CONV_FWD_LDS_BYTES); SETATTR(k_conv_bwd, CONV_BWD_LDS_BYTES); SETATTR(k_mix2, CONV_BWD_LDS_BYTES);
@@ -1824,36 +2089,52 @@ static int enqueue_step_t(az_trainer *t) {
     }
     {   // per instantiation: the largest batch this configuration serves (set every time: cheap, and correct across batch sizes)
         const int fmax = fc_lds_bytes(NW, RTM * 16);
-        SETATTR((k_fc_fwd<RTM, NW, PF>), fmax); SETATTR((k_fc_dgrad<RTM, NW, PF>), fmax); SETATTR((k_mix1<RTM, NW, PF>), fmax);
-        SETATTR((k_heads_bwd<RTM, NT>), RTM * 16 * 16 * 4 + 512 * 8);
+        SETATTR((k_fc_fwd<RTM, NW, PF, SPLIT>), fmax); SETATTR((k_fc_dgrad<RTM, NW, PF, SPLIT>), fmax); SETATTR((k_mix1<RTM, NW, PF, SPLIT>), fmax);
+        SETATTR((k_heads_bwd<RTM, NT, SPLIT>), RTM * 16 * 16 * 4 + 768 * 8);
     }
 #undef SETATTR
     const dim3 tb(TPB), tw(NW * 64);
     hipLaunchKernelGGL(k_conv1_fwd, dim3(d.NB), tb, 0, st, d, q);
     for (int l = 1; l <= 3; ++l) hipLaunchKernelGGL(k_conv_fwd, dim3(d.NB), tb, CONV_FWD_LDS_BYTES, st, d, q, l);
-    hipLaunchKernelGGL((k_fc_fwd<RTM, NW, PF>), dim3(d.F1 / 16), tw, fcl, st, d, q, 1);
-    hipLaunchKernelGGL((k_fc_fwd<RTM, NW, PF>), dim3(d.F2 / 16), tw, fcl, st, d, q, 2);
+    hipLaunchKernelGGL((k_fc_fwd<RTM, NW, PF, SPLIT>), dim3(d.F1 / 16, NRB), tw, fcl, st, d, q, 1);
+    if (SPLIT) hipLaunchKernelGGL(k_fc_fin, dim3(d.F1 / 16, NRB), tb, 0, st, d, q, 1);
+    hipLaunchKernelGGL((k_fc_fwd<RTM, NW, PF, SPLIT>), dim3(d.F2 / 16, NRB), tw, fcl, st, d, q, 2);
+    if (SPLIT) hipLaunchKernelGGL(k_fc_fin, dim3(d.F2 / 16, NRB), tb, 0, st, d, q, 2);
     hipLaunchKernelGGL((k_heads_fwd<NT, 8>), dim3(d.B / 16), dim3(8 * 64), 0, st, d, q);
-    hipLaunchKernelGGL((k_heads_bwd<RTM, NT>), dim3(d.F2 / 16), tb, hbl, st, d, q);
-    hipLaunchKernelGGL((k_fc_dgrad<RTM, NW, PF>), dim3(d.F1 / 16), tw, fcl, st, d, q);
-    const int nw2 = fc_wgrad_blocks(d.F2, d.F1, NW), nw1 = fc_wgrad_blocks(d.F1, d.FIN, 4);
-    hipLaunchKernelGGL((k_mix1<RTM, NW, PF>), dim3(nw2 + d.FIN / 16), tw, fcl, st, d, q, nw2);
+    hipLaunchKernelGGL((k_heads_bwd<RTM, NT, SPLIT>), dim3(d.F2 / 16, NRB), tb, hbl, st, d, q);
+    if (SPLIT) hipLaunchKernelGGL(k_bn1d_bwd_fin, dim3(d.F2 / 16, NRB), tb, 0, st, d, q, 2);
+    hipLaunchKernelGGL((k_fc_dgrad<RTM, NW, PF, SPLIT>), dim3(d.F1 / 16, NRB), tw, fcl, st, d, q);
+    if (SPLIT) hipLaunchKernelGGL(k_bn1d_bwd_fin, dim3(d.F1 / 16, NRB), tb, 0, st, d, q, 1);
+    const int nw2 = fc_wgrad_blocks(d.F2, d.F1, SPLIT ? NW / 4 : NW), nw1 = fc_wgrad_blocks(d.F1, d.FIN, 4);
+    hipLaunchKernelGGL((k_mix1<RTM, NW, PF, SPLIT>), dim3(nw2 + (d.FIN / 16) * NRB), tw, fcl, st, d, q, nw2);
     hipLaunchKernelGGL(k_mix2, dim3(nw1 + d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, nw1);
     hipLaunchKernelGGL(k_conv_bwd, dim3(d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, 2);
     hipLaunchKernelGGL(k_conv_bwd, dim3(d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, 1);
     hipLaunchKernelGGL(k_conv1_bwd, dim3(d.NB), tb, 0, st, d, q);
-    hipLaunchKernelGGL(k_update, dim3((UPD_ALL + TPB - 1) / TPB + 1), tb, 0, st, d, q);
+    hipLaunchKernelGGL(k_update, dim3((UPD_ALL + 63) / 64 + 4), tb, 0, st, d, q);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
 
-template <int RTM, int NW, int PF>
+template <int RTM, int NW, int PF, bool SPLIT = false>
 static int enqueue_step_r(az_trainer *t) {
     switch (t->d.NHP) {
-        case 16: return enqueue_step_t<RTM, NW, PF, 1>(t);
-        case 48: return enqueue_step_t<RTM, NW, PF, 3>(t);
-        default: return enqueue_step_t<RTM, NW, PF, 5>(t);
+        case 16: return enqueue_step_t<RTM, NW, PF, 1, SPLIT>(t);
+        case 48: return enqueue_step_t<RTM, NW, PF, 3, SPLIT>(t);
+        default: return enqueue_step_t<RTM, NW, PF, 5, SPLIT>(t);
     }
+}
+
+// rows per row block of the dense kernels for batch size B: 0 = no split (a workgroup sees all rows of its 16 columns: <= 128 rows,
+// where sixteen or eight waves splitting K keep a 16-column workgroup short); above, blocks of 64 rows (the batch-64 configuration:
+// sixteen waves split K) up to 368 rows and of 128 rows (eight waves) from 384 on, so that fc1 / fc2 run 4 x 64 / 4 x 32 workgroups at
+// batch 512 instead of 64 / 32 (measured, ms per step at 256 / 512: unsplit 0.412 / 0.658, blocks of 64 0.315 / 0.442, of 128
+// 0.337 / 0.408).  AZ_TRAIN_RB = 0 / 64 / 128 overrides.
+static int dense_row_block(int B) {
+    static int force = -2;
+    if (force == -2) { const char *e = getenv("AZ_TRAIN_RB"); force = e ? atoi(e) : -1; }
+    if (force == 0 || ((force == 64 || force == 128) && B > force)) return force;
+    return B > 128 ? (B >= 384 ? 128 : 64) : 0;
 }
 
 static int enqueue_step(az_trainer *t) {  // (row tiles, waves that split K, prefetch depth) by batch size: see "dense layers: shared pieces"
@@ -1868,6 +2149,7 @@ static int enqueue_step(az_trainer *t) {  // (row tiles, waves that split K, pre
         return AZ_OK;
     }
     const int RT = t->d.B / 16;
+    if (t->d.NRB > 1) return t->d.RB == 64 ? enqueue_step_r<4, 16, 1, true>(t) : enqueue_step_r<8, 8, 1, true>(t);
     if (RT <= 4) return enqueue_step_r<4, 16, 1>(t);
     if (RT <= 8) return enqueue_step_r<8, 8, 1>(t);
     if (RT <= 16) return enqueue_step_r<16, 4, 1>(t);
@@ -1913,6 +2195,8 @@ extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const floa
         int S = force == 1 || force == 2 || force == 4 ? force : 1;
         while (S > 1 && B * S > 256) S >>= 1;
         t->d.B = B; t->d.S = S; t->d.NB = B * S < 256 ? B * S : 256;
+        const int rb = dense_row_block(B);
+        t->d.RB = rb ? rb : B; t->d.NRB = rb ? (B + rb - 1) / rb : 1;
     }
     t->q.state = d_state; t->q.pi = d_pi; t->q.z = d_z; t->q.perm = (const long long *)d_perm; t->q.loss_pi = d_loss_pi; t->q.loss_v = d_loss_v;
     t->tq.state = d_state; t->tq.pi = d_pi; t->tq.z = d_z; t->tq.perm = (const long long *)d_perm; t->tq.loss_pi = d_loss_pi; t->tq.loss_v = d_loss_v;

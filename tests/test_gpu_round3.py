@@ -115,17 +115,17 @@ def test_bench_launches_its_own_ranks(tmp_path):
         assert kinds == sorted(kinds)
 
 
-def test_bench_rehearsal_with_six_ranks_and_idle_ranks():
+def test_bench_rehearsal_with_five_ranks_and_an_idle_rank():
     """VERDICT r3 item 3 (GPU half).  The N = 8 control flow -- sharded waves, the packed sample all-gather, config 3, the trainer loop
-    with rank 0 training and the others waiting for the weights, the sharded arena -- rehearsed with SIX ranks: a one-GPU box of this
-    pool admits at most six processes on its card, so eight ranks cannot be started here (the world-8 arithmetic and collectives run on
-    the CPU in tests/test_dist.py::test_world8_with_fewer_units_than_ranks).  config 5 runs with 4 evaluation games -> two of the six
-    ranks play no arena round; its results must equal a single process's."""
-    out = _rehearse(6, "--games", "32", "--saturated-games", "0", "--config3-total", "96", "--config5-episodes", "64",
+    with rank 0 training and the others waiting for the weights, the sharded arena -- rehearsed with FIVE ranks: a one-GPU box of this
+    pool admits at most six processes on its card and this test process is one of them, so eight ranks cannot be started here (the
+    world-8 arithmetic and collectives run on the CPU in tests/test_dist.py::test_world8_with_fewer_units_than_ranks).  config 5 runs
+    with 4 evaluation games -> the fifth rank plays no arena round; its results must equal a single process's."""
+    out = _rehearse(5, "--games", "32", "--saturated-games", "0", "--config3-total", "80", "--config5-episodes", "64",
                     "--config5-variants", "reference_batch_64", "--config5-eval-episodes", "4")
-    assert out["n_gpus"] == 6 and len(out["per_rank_ms_per_step"]) == 6 and all(t > 0 for t in out["per_rank_ms_per_step"])
+    assert out["n_gpus"] == 5 and len(out["per_rank_ms_per_step"]) == 5 and all(t > 0 for t in out["per_rank_ms_per_step"])
     assert out["config"]["concurrent_games_per_gpu"] == 32 and abs(out["plies_per_game"] - 60.5) < 3
-    assert out["config3"]["concurrent_games_per_gpu"] == 16 and out["config3"]["n_gpus"] == 6
+    assert out["config3"]["concurrent_games_per_gpu"] == 16 and out["config3"]["n_gpus"] == 5
     multi = out["config5"]["variants"]["reference_batch_64"]["iterations"]
     import bench
     bench._imports()
