@@ -112,13 +112,22 @@ def lib():
     return L
 
 
-def csrc_tree_hash():
-    """sha256[:16] over the sources libaz_amd.so is built from: counter files under profiles/ carry the hash of the tree they
+# the sources a measurement depends on: counter files of the network kernels stay valid while only the engine or the training step
+# changes, and the other way round
+CSRC_COMPONENTS = {"net": ("az_net.hip",), "engine": ("az_engine.hip",), "train": ("az_train.hip",)}
+_CSRC_SHARED = ("az_device.h", "az_host.h", "az_common.hip", "Makefile")
+
+
+def csrc_tree_hash(component=None):
+    """sha256[:16] over the sources libaz_amd.so is built from (component None: the whole csrc tree; "net" / "engine" / "train": that
+    file plus the shared headers, the Makefile and include/az_amd.h): counter files under profiles/ carry the hash of the sources they
     were measured on, bench.py drops them when it differs from the running build"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(_HERE, "csrc")
     for name in sorted(os.listdir(d)):
+        if component is not None and name not in CSRC_COMPONENTS[component] + _CSRC_SHARED:
+            continue
         if name.endswith((".hip", ".h")) or name == "Makefile":
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())

@@ -97,10 +97,11 @@ def stamped(name):
     if not os.path.exists(path):
         return None, "no such file"
     d = json.load(open(path))
-    have, want = d.get("csrc_sha"), _lib.csrc_tree_hash()
+    comp = d.get("csrc_component")  # which sources the measurement depends on (None: the whole tree)
+    have, want = d.get("csrc_sha"), _lib.csrc_tree_hash(comp)
     if have != want:
-        return None, f"profiles/{name} was measured on csrc tree {have}, this build is {want}: dropped"
-    return d, f"profiles/{name}, csrc tree {have}"
+        return None, f"profiles/{name} was measured on csrc {comp or 'tree'} {have}, this build is {want}: dropped"
+    return d, f"profiles/{name}, csrc {comp or 'tree'} {have}"
 
 
 # ------------------------------------------------------------------------------------------------ self-launch

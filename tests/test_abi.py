@@ -67,3 +67,11 @@ def test_counter_files_are_used_only_for_the_tree_they_were_measured_on(tmp_path
     d, why = bench.stamped("traffic.json")
     assert d is None and "dropped" in why
     assert bench.stamped("missing.json")[0] is None
+    # a file stamped for one component (the network kernels) is judged by that component's sources alone
+    hn = _lib.csrc_tree_hash("net")
+    assert hn != h and hn != _lib.csrc_tree_hash("engine") and hn != _lib.csrc_tree_hash("train")
+    (prof / "traffic.json").write_text(json.dumps({"othello_4096": {"k_trunk": 2}, "csrc_component": "net", "csrc_sha": hn}))
+    d, why = bench.stamped("traffic.json")
+    assert d and d["othello_4096"]["k_trunk"] == 2 and "net" in why
+    (prof / "traffic.json").write_text(json.dumps({"othello_4096": {"k_trunk": 2}, "csrc_component": "net", "csrc_sha": h}))
+    assert bench.stamped("traffic.json")[0] is None

@@ -137,9 +137,10 @@ sys.path.insert(0, root)
 from alphazero_amd._lib import csrc_tree_hash  # noqa: E402
 
 # the hash of the sources the measured library was built from: bench.py uses a counter file only for the same tree
-for d in (traffic, mfma, kstep):
+for d, comp in ((traffic, "net"), (mfma, "net"), (kstep, "engine")):
     if d:
-        d["csrc_sha"] = csrc_tree_hash()
+        d["csrc_component"] = comp  # the network kernels' counters stay valid while only the engine or the training step changes
+        d["csrc_sha"] = csrc_tree_hash(comp)
 if traffic:
     json.dump(traffic, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
 if mfma:
