@@ -200,15 +200,18 @@ def test_backends_are_selectable_and_unsupported_shapes_use_the_stock_step():
     assert not train_step.supports(odd, 64)
 
 
-def test_dropout_law_and_determinism():
+@pytest.mark.parametrize("B", [128, 272, 512])
+def test_dropout_law_and_determinism(B):
     """the step's dropout: the kept fraction of the units that pass the ReLU is 1 - p, kept units are scaled by 1 / (1 - p), masks
-    differ from step to step and between the two layers, and a second run with the same seed reproduces the losses and weights bit for bit"""
+    differ from step to step and between the two layers, and a second run with the same seed reproduces the losses and weights bit for
+    bit -- at 128 rows (a dense workgroup sees all rows) and on the row-split path (272 = four blocks of 64 and one of 16; 512 = four of
+    128), whose statistics, heads gradient and weight-gradient tiles are combined from partials in a fixed order"""
     import check_train_step as C
     from alphazero_amd.train_step import HipTrainStep
     net = C.make_net("othello8", 3).cuda()
-    state, pi, z = C.make_samples(net, 400)
-    B, p = 128, 0.3
-    perm = torch.randperm(400, generator=torch.Generator().manual_seed(1))[: 3 * B].cuda().contiguous()
+    state, pi, z = C.make_samples(net, 3 * B + 16)
+    p = 0.3
+    perm = torch.randperm(3 * B + 16, generator=torch.Generator().manual_seed(1))[: 3 * B].cuda().contiguous()
 
     def run():
         hip = HipTrainStep(net, max_batch=B)
