@@ -2,7 +2,8 @@
 """Randomised stress of the hand-written training step: 10 network / batch / dropout configurations x 6 data seeds against torch autograd in
 float64 (tools/check_train_step.py).  A configuration above the bound is printed with its first buffers; a lone ReLU tie between float32
 and float64 shows as ONE element of one dy buffer off at step 0 and errors everywhere from step 1 on (run check_train_step.py on the case
-to see where the error sits).  Last run (round 3, MI355X): 60 cases, 3 above the bound, each a single-unit tie."""
+to see where the error sits).  Last run (round 4, MI355X, profiles/r04_stress_train.txt): 60 cases, 3 above the bound, each a tie in a conv layer -- the one on the row-split
+path (othello8, batch 512, seed 6) shows the same five buffers with the same errors unsplit and with row blocks of 64 / 128 (AZ_TRAIN_RB)."""
 import sys, os
 sys.path.insert(0, "tools")
 import check_train_step as C
