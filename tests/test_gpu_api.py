@@ -427,3 +427,25 @@ def test_trainer_two_ranks_equal_one_rank(tmp_path):
     # the evaluation rounds are sharded over the ranks: same games, same stats as a single process
     assert torch.equal(tr.nn.fc1.weight.detach().cpu(), a["w"])
     assert dict(tr.eval_results["results"][0]) == a["eval"], (tr.eval_results["results"][0], a["eval"])
+
+
+def test_timers_on_the_device():
+    """the reference's benchmarking idiom (timers.py:32-76, 120-151) through the mirror: a self-play game of the single-game player,
+    the same games at once on the lock-step engine, and the optimisation step -- stock PyTorch and the hand-written HIP step"""
+    from alphazero_amd.games.othello import OthelloConfig
+    from alphazero_amd.timers import NeuralTimer, SelfPlayTimer
+    np.random.seed(0)
+    torch.manual_seed(0)
+    cfg = OthelloConfig(board_size=6, simulations=12, device="cuda", batch_size=32)
+    spt = SelfPlayTimer("othello", cfg)
+    secs, moves = spt.self_play()
+    assert secs > 0 and 28 <= moves <= 40 and spt.board.is_game_over()
+    mean_t, mean_s = spt.timeit(n_episodes=2)
+    assert mean_t > 0 and 28 <= mean_s <= 40
+    spt.timeit_batched(64)
+    per_game, plies = spt.timeit_batched(64)
+    assert 0 < per_game < mean_t and 28 <= plies <= 40  # 64 games at once cost less per game than one alone
+    nt = NeuralTimer("othello", cfg)
+    assert nt.timeit(n_batches=3) > 0
+    t_hip = nt.timeit_hip(n_batches=60, n_samples=512)
+    assert 0 < t_hip < 5e-3
