@@ -1217,8 +1217,12 @@ static int do_search(az_engine *e, int n_sim) {
     // graph replay needs launch parameters that do not change from search to search: the Philox counter base must be 0
     // (one search per root, as in self-play and the arena), no per-launch event recording, and a quantised batch cap
     const bool graphable = e->graphs_ok && d.sim_base == 0 && !(e->net && az_net_profiling(e->net));
-    if (!graphable) return enqueue_search(e, n_sim, cap);
-    cap = (d.G >= 4096 && cap < 4096) ? (cap + 511) / 512 * 512 : d.G;  // below 4096 rows the network picks other kernels
+    // the quantised cap of the graph path also when the search runs as plain launches under az_net_profile: the profiled step then
+    // launches the kernels the timed (graph-replayed) steps launch (an exact cap of 4095 -- one game of 4096 over, as happens from
+    // ply ~11 on: Othello has early wipe-outs -- would hand the trunk to the one-board-per-wave kernel for the rest of the wave)
+    const int cap_q = (d.G >= 4096 && cap < 4096) ? (cap + 511) / 512 * 512 : d.G;  // below 4096 rows the network picks other kernels
+    if (!graphable) return enqueue_search(e, n_sim, (e->net && az_net_profiling(e->net) && d.sim_base == 0) ? cap_q : cap);
+    cap = cap_q;
     const unsigned long long key = ((unsigned long long)n_sim << 32) | (unsigned)cap;
     auto it = e->graphs.find(key);
     if (it != e->graphs.end()) {

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "az_device.h"
+#include <hip/hip_ext.h>
 #include "az_host.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -2403,12 +2404,17 @@ struct az_net {
     // live per-stage timing (az_net_profile): HIP events around every stage launch, harvested in batches
     bool prof = false;
     int last_trunk_two_boards = 0;
-    std::vector<hipEvent_t> prof_ev;  // [PROF_SLOTS][5]
+    std::vector<hipEvent_t> prof_ev;  // [PROF_SLOTS][4 stages][start, stop]
+    std::vector<int> prof_has;        // bit s: stage s of that forward launched a kernel (the fused Connect4 tail: stage 1 only)
     std::vector<int> prof_kind;       // trunk kernel used by the forward in that slot
     int prof_used = 0;
-    double prof_empty_ms = -1.0;  // what an event-to-event interval costs with NO kernel in it (calibrated on first use)
-    double prof_ms[5] = {0, 0, 0, 0, 0};  // k_trunk2, fc1, fc2, heads, k_trunk (one board per wave)
-    long long prof_n[5] = {0, 0, 0, 0, 0};
+    double prof_empty_ms = 0.0;   // kept for az_net_profile_overhead: the start / stop events of a launch need no correction
+    int last_trunk_q = 0;
+    // k_trunk2, fc1 / fc2 on the tiled GEMMs (k_gemm, k_gemm_solo, k_gemm_solo_t; Connect4Net: the fused tail in the fc1 slot), heads,
+    // k_trunk (one board per wave) | fc1 / fc2 on the small-batch kernels (k_dense_frag, k_dense_small), k_trunk_q: a slot per KERNEL
+    // family, so that a slot's mean is the figure rocprofv3 lists for that kernel
+    double prof_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 #define PROF_SLOTS 2048
 
@@ -2887,6 +2893,18 @@ static bool use_wino(int CH, int CW) {
     return (CH == 8 && CW == 8) || (CH == 7 && CW == 6);  // AZ_WINOGRAD=0: direct form everywhere (the oracle follows the same variable)
 }
 
+// Every forward kernel is launched through AZ_LAUNCH.  Under az_net_profile the launch carries a start and a stop event
+// (hipExtLaunchKernelGGL): they take the dispatch's own begin / end timestamps -- the two numbers rocprofv3 reports a kernel's duration
+// from -- so a slot's mean IS that kernel's average duration, with nothing to calibrate away (events recorded BETWEEN launches measure
+// marker to marker: kernel + 3-5 us of dispatch and marker processing).  Otherwise (and inside a graph capture) it is a plain launch.
+static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static int g_ev_used = 0;
+#define AZ_LAUNCH(kern, grid, block, lds, st, ...)                                                                           \
+    do {                                                                                                                     \
+        if (g_ev_start) { hipExtLaunchKernelGGL(kern, grid, block, lds, st, g_ev_start, g_ev_stop, 0, __VA_ARGS__); g_ev_used = 1; } \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                    \
+    } while (0)
+
 template <int CH, int CW, bool WINO>
 static int launch_trunk2(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
     using G = TrunkGeom<CH, CW>;
@@ -2906,7 +2924,7 @@ static int launch_trunk2(az_net *n, const float *in, int B, const int *dyn, hipS
         n_cu = pr.multiProcessorCount;
     }
     const int pairs = (B + 1) / 2, want = (pairs + 3) / 4;
-    hipLaunchKernelGGL((k_trunk2<CH, CW, WPB, WINO>), dim3(want < n_cu ? want : n_cu), dim3(64 * WPB), lds_bytes, st, in, B, dyn, n->tp, n->feat);
+    AZ_LAUNCH((k_trunk2<CH, CW, WPB, WINO>), dim3(want < n_cu ? want : n_cu), dim3(64 * WPB), lds_bytes, st, in, B, dyn, n->tp, n->feat);
     return AZ_OK;
 }
 
@@ -2920,13 +2938,15 @@ static int launch_trunk(az_net *n, const float *in, int B, const int *dyn, hipSt
     // two boards per wave on 32x32x2 pays from ~4096 boards up (16384: 325 vs 331 us); below that the one-board-
     // per-wave kernel fills the chip better (2048: 45 vs 77 us).  AZ_TRUNK_V1=1 forces the latter.
     n->last_trunk_two_boards = (!trunk_v1() && B >= 4096) ? 1 : 0;
+    n->last_trunk_q = 0;
     if (n->last_trunk_two_boards) return launch_trunk2<CH, CW, WINO>(n, in, B, dyn, st);
     if (B <= trunk_q_max()) {  // few boards: four waves per board (k_trunk_q)
+        n->last_trunk_q = 1;
         static int nw_env = -1;
         if (nw_env < 0) { const char *e = getenv("AZ_TRUNK_Q_WAVES"); nw_env = e ? atoi(e) : 0; }
         const int nw = nw_env ? nw_env : (B <= 256 ? 8 : 4);  // eight waves per board while that leaves a SIMD at most two (11.7 vs 13.2 us; 512 boards: 23.0 vs 18.6)
-        if (nw == 8) hipLaunchKernelGGL((k_trunk_q<CH, CW, WINO, 8>), dim3((unsigned)B), dim3(512), 0, st, in, B, dyn, n->tp, n->feat);
-        else hipLaunchKernelGGL((k_trunk_q<CH, CW, WINO, 4>), dim3((unsigned)B), dim3(256), 0, st, in, B, dyn, n->tp, n->feat);
+        if (nw == 8) AZ_LAUNCH((k_trunk_q<CH, CW, WINO, 8>), dim3((unsigned)B), dim3(512), 0, st, in, B, dyn, n->tp, n->feat);
+        else AZ_LAUNCH((k_trunk_q<CH, CW, WINO, 4>), dim3((unsigned)B), dim3(256), 0, st, in, B, dyn, n->tp, n->feat);
         return AZ_OK;
     }
     using G = TrunkGeom<CH, CW>;
@@ -2941,7 +2961,7 @@ static int launch_trunk(az_net *n, const float *in, int B, const int *dyn, hipSt
         AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trunk<CH, CW, WINO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_trunk<CH, CW, WINO>), dim3((B + 3) / 4), dim3(256), lds_bytes, st, in, B, dyn, n->tp, n->feat);
+    AZ_LAUNCH((k_trunk<CH, CW, WINO>), dim3((B + 3) / 4), dim3(256), lds_bytes, st, in, B, dyn, n->tp, n->feat);
     return AZ_OK;
 }
 
@@ -2955,8 +2975,8 @@ static int gemm_launch(const float *A, const float *Bw, const float *bias, float
         attr_set = true;
     }
     dim3 grid(N / BN, (M + BM - 1) / BM);
-    if (relu) hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, true, KT>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
-    else hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, false, KT>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+    if (relu) AZ_LAUNCH((k_gemm<BM, BN, WM, WN, true, KT>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+    else AZ_LAUNCH((k_gemm<BM, BN, WM, WN, false, KT>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
     return AZ_OK;
 }
 
@@ -2984,8 +3004,8 @@ static int solo_t_launch(const float *A, const float *Bw, const float *bias, flo
         attr_set = true;
     }
     dim3 grid(N / BN, (M + BM - 1) / BM);
-    if (relu) hipLaunchKernelGGL((k_gemm_solo_t<true, TM, TN>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
-    else hipLaunchKernelGGL((k_gemm_solo_t<false, TM, TN>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+    if (relu) AZ_LAUNCH((k_gemm_solo_t<true, TM, TN>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+    else AZ_LAUNCH((k_gemm_solo_t<false, TM, TN>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
     return AZ_OK;
 }
 
@@ -3031,19 +3051,22 @@ static int frag_go(const float *A, const float *Bq, const float *bias, float *C,
         attr_lds = lds;
     }
     dim3 grid((unsigned)(N / (16 * NT)), (unsigned)((M + 15) / 16));
-    if (relu) hipLaunchKernelGGL((k_dense_frag<true, NT>), grid, dim3(64 * NT), lds, st, A, Bq, bias, C, M, N, K, dyn);
-    else hipLaunchKernelGGL((k_dense_frag<false, NT>), grid, dim3(64 * NT), lds, st, A, Bq, bias, C, M, N, K, dyn);
+    if (relu) AZ_LAUNCH((k_dense_frag<true, NT>), grid, dim3(64 * NT), lds, st, A, Bq, bias, C, M, N, K, dyn);
+    else AZ_LAUNCH((k_dense_frag<false, NT>), grid, dim3(64 * NT), lds, st, A, Bq, bias, C, M, N, K, dyn);
     return AZ_OK;
 }
+
+static int g_last_gemm_small = 0;  // set by launch_gemm when it served the layer with a small-batch kernel (the profiler books those apart)
 
 static int launch_gemm(const float *A, const float *Bw, const float *Bq, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
     AZ_REQUIRE(K % 32 == 0, AZ_EINVAL, "GEMM K=%d is not a multiple of 32", K);
     switch (gemm_kind(M, N, K, Bq != nullptr)) {
-        case GK_FRAG: return frag_go(A, Bq, bias, C, M, N, K, relu, dyn, st);
+        case GK_FRAG: g_last_gemm_small = 1; return frag_go(A, Bq, bias, C, M, N, K, relu, dyn, st);
         case GK_SMALL: {
+            g_last_gemm_small = 1;
             dim3 grid((unsigned)((N + 63) / 64), (unsigned)M);
-            if (relu) hipLaunchKernelGGL((k_dense_small<true>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
-            else hipLaunchKernelGGL((k_dense_small<false>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
+            if (relu) AZ_LAUNCH((k_dense_small<true>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
+            else AZ_LAUNCH((k_dense_small<false>), grid, dim3(64), 0, st, A, Bw, bias, C, M, N, K, dyn);
             return AZ_OK;
         }
         case GK_SOLO: {
@@ -3055,8 +3078,8 @@ static int launch_gemm(const float *A, const float *Bw, const float *Bq, const f
                 attr_set = true;
             }
             dim3 grid(N / 256, (M + 255) / 256);
-            if (relu) hipLaunchKernelGGL((k_gemm_solo<true>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
-            else hipLaunchKernelGGL((k_gemm_solo<false>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+            if (relu) AZ_LAUNCH((k_gemm_solo<true>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
+            else AZ_LAUNCH((k_gemm_solo<false>), grid, dim3(256), lds, st, A, Bw, bias, C, M, N, K, dyn);
             return AZ_OK;
         }
         case GK_SOLO_T: return solo_t_launch<2, 2>(A, Bw, bias, C, M, N, K, relu, dyn, st);
@@ -3089,7 +3112,7 @@ static int heads_go(az_net *n, int B, float *probs, float *value, const int *dyn
         AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_heads<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_heads<NT>), dim3((B + 31) / 32), dim3(256), lds, st, n->h2, n->hw, n->hb, B, n->F2, n->A, probs, value, dyn);
+    AZ_LAUNCH((k_heads<NT>), dim3((B + 31) / 32), dim3(256), lds, st, n->h2, n->hw, n->hb, B, n->F2, n->A, probs, value, dyn);
     return AZ_OK;
 }
 
@@ -3102,7 +3125,7 @@ static int heads2_go(az_net *n, int B, float *probs, float *value, const int *dy
         AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_heads2<NT, RH, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_heads2<NT, RH, 512>), dim3((unsigned)((B + 16 * RH - 1) / (16 * RH))), dim3(64 * NT), lds, st, n->h2, n->hwq, n->hb, B, n->A,
+    AZ_LAUNCH((k_heads2<NT, RH, 512>), dim3((unsigned)((B + 16 * RH - 1) / (16 * RH))), dim3(64 * NT), lds, st, n->h2, n->hwq, n->hb, B, n->A,
                        probs, value, dyn);
     return AZ_OK;
 }
@@ -3118,7 +3141,7 @@ static int heads_small_max(const az_net *n) {
 
 static int launch_heads(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
     if (B <= heads_small_max(n) && n->NH <= 128 && n->F2 % 32 == 0) {  // few rows: latency, not throughput
-        hipLaunchKernelGGL(k_heads_small, dim3((unsigned)B), dim3(128), 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, n->NH, probs, value, dyn);
+        AZ_LAUNCH(k_heads_small, dim3((unsigned)B), dim3(128), 0, st, n->h2, n->hw, n->hb, B, n->F2, n->A, n->NH, probs, value, dyn);
         return AZ_OK;
     }
     static int v1 = -1;
@@ -3158,14 +3181,14 @@ static int tail_go(az_net *n, int B, float *probs, float *value, const int *dyn,
         AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tail_small<FIN, 64, 32, 16, A, R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_tail_small<FIN, 64, 32, 16, A, R>), dim3((unsigned)((B + 4 * R - 1) / (4 * R))), dim3(256), lds, st, n->feat, n->fc1w,
+    AZ_LAUNCH((k_tail_small<FIN, 64, 32, 16, A, R>), dim3((unsigned)((B + 4 * R - 1) / (4 * R))), dim3(256), lds, st, n->feat, n->fc1w,
                        n->fc1b, n->fc2w, n->fc2b, n->hw, n->hb, B, probs, value, dyn);
     return AZ_OK;
 }
 
 static int launch_tail(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
     if (!tail_v1()) {
-        hipLaunchKernelGGL((k_tail_mfma<192, 64, 32, 16, 7>), dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, n->feat, n->fc1w, n->fc1b, n->fc2w,
+        AZ_LAUNCH((k_tail_mfma<192, 64, 32, 16, 7>), dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, n->feat, n->fc1w, n->fc1b, n->fc2w,
                            n->fc2b, n->hw, n->hb, B, probs, value, dyn);
         return AZ_OK;
     }
@@ -3187,7 +3210,7 @@ static int launch_trunk_plain(az_net *n, const float *in, int B, const int *dyn,
         attr_set = true;
     }
     n->last_trunk_two_boards = 0;
-    hipLaunchKernelGGL((k_trunk<CH, CW, false>), dim3((B + 3) / 4), dim3(256), lds_bytes, st, in, B, dyn, n->tp, n->feat);
+    AZ_LAUNCH((k_trunk<CH, CW, false>), dim3((B + 3) / 4), dim3(256), lds_bytes, st, in, B, dyn, n->tp, n->feat);
     return AZ_OK;
 }
 
@@ -3215,12 +3238,21 @@ static int run_stage(az_net *n, int stage, const float *d_input, int B, const in
 
 static int prof_harvest(az_net *n) {
     if (n->prof_used == 0) return AZ_OK;
-    AZ_HIP(hipEventSynchronize(n->prof_ev[(size_t)(n->prof_used - 1) * 5 + 4]));
+    for (int i = n->prof_used - 1; i >= 0; --i) {  // wait for the last launch that carries events
+        int last = -1;
+        for (int s = 3; s >= 0 && last < 0; --s) if (n->prof_has[i] & (1 << s)) last = s;
+        if (last >= 0) { AZ_HIP(hipEventSynchronize(n->prof_ev[((size_t)i * 4 + last) * 2 + 1])); break; }
+    }
     for (int i = 0; i < n->prof_used; ++i)
         for (int s = 0; s < 4; ++s) {
+            if (!(n->prof_has[i] & (1 << s))) continue;
             float ms = 0.0f;
-            AZ_HIP(hipEventElapsedTime(&ms, n->prof_ev[(size_t)i * 5 + s], n->prof_ev[(size_t)i * 5 + s + 1]));
-            const int slot = (s == 0 && !n->prof_kind[i]) ? 4 : s;
+            AZ_HIP(hipEventElapsedTime(&ms, n->prof_ev[((size_t)i * 4 + s) * 2], n->prof_ev[((size_t)i * 4 + s) * 2 + 1]));
+            const int kind = n->prof_kind[i];  // bit 0: k_trunk2, bit 1: k_trunk_q, bit 2 / 3: fc1 / fc2 on a small-batch kernel
+            int slot = s;
+            if (s == 0) slot = (kind & 1) ? 0 : ((kind & 2) ? 7 : 4);
+            else if (s == 1 && (kind & 4)) slot = 5;
+            else if (s == 2 && (kind & 8)) slot = 6;
             n->prof_ms[slot] += ms;
             n->prof_n[slot] += 1;
         }
@@ -3228,52 +3260,37 @@ static int prof_harvest(az_net *n) {
     return AZ_OK;
 }
 
-// az_net_profile(net, 1): every forward from now on brackets its four stage launches with HIP events on the
-// forward's stream; az_net_profile_read harvests them: total ms and launch count of k_trunk2, k_gemm fc1, k_gemm fc2,
-// k_heads and (index 4) the one-board-per-wave k_trunk.  The events cost ~1 us per launch on the host side.
+// az_net_profile(net, 1): every forward from now on launches its stage kernels with a start and a stop event each
+// (AZ_LAUNCH); az_net_profile_read harvests them: total ms and launch count per kernel family (include/az_amd.h).
 extern "C" int az_net_profile(az_net *n, int enable) {
     AZ_REQUIRE(n, AZ_EINVAL, "null net");
     if (enable && n->prof_ev.empty()) {
-        n->prof_ev.resize((size_t)PROF_SLOTS * 5);
+        n->prof_ev.resize((size_t)PROF_SLOTS * 8);
         n->prof_kind.assign(PROF_SLOTS, 0);
+        n->prof_has.assign(PROF_SLOTS, 0);
         for (auto &e : n->prof_ev) AZ_HIP(hipEventCreate(&e));
     }
-    if (enable) { n->prof_used = 0; for (int i = 0; i < 5; ++i) { n->prof_ms[i] = 0; n->prof_n[i] = 0; } }
+    if (enable) { n->prof_used = 0; for (int i = 0; i < 8; ++i) { n->prof_ms[i] = 0; n->prof_n[i] = 0; } }
     n->prof = enable != 0;
     return AZ_OK;
 }
 
 extern "C" int az_net_profiling(const az_net *n) { return n && n->prof ? 1 : 0; }
 
-// An interval between two recorded events is not only the kernel between them: the marker packets and the dispatch
-// cost ~5 us per interval on this stack, which matters for kernels of 10-60 us.  Calibration: 64 events recorded back to
-// back on the stream, the mean gap is the cost of an EMPTY interval; az_net_profile_overhead reports it so that callers
-// can subtract it per launch (the corrected figure is the one that agrees with rocprofv3's kernel durations).
-static int prof_calibrate(az_net *n, hipStream_t st) {
-    constexpr int N = 64;
-    hipEvent_t ev[N + 1];
-    for (int i = 0; i <= N; ++i) AZ_HIP(hipEventCreate(&ev[i]));
-    for (int rep = 0; rep < 2; ++rep) {  // the first burst warms the path
-        for (int i = 0; i <= N; ++i) AZ_HIP(hipEventRecord(ev[i], st));
-        AZ_HIP(hipEventSynchronize(ev[N]));
-    }
-    double tot = 0.0;
-    for (int i = 0; i < N; ++i) { float ms = 0.0f; AZ_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); tot += ms; }
-    for (int i = 0; i <= N; ++i) (void)hipEventDestroy(ev[i]);
-    n->prof_empty_ms = tot / N;
-    return AZ_OK;
-}
-
+// Round 1-3 recorded events BETWEEN the launches and subtracted the calibrated cost of an empty event-to-event interval (4.6-4.9 us);
+// against rocprofv3's per-dispatch table that over-corrects a 35 us kernel by ~1.9 us (a marker behind a kernel is processed while the
+// kernel runs; two markers back to back are not).  With start / stop events on the launch itself there is nothing to subtract:
+// az_net_profile_overhead reports 0 and stays for callers that subtract it.
 extern "C" int az_net_profile_overhead(az_net *n, double *ms_per_interval) {
     AZ_REQUIRE(n && ms_per_interval, AZ_EINVAL, "null argument");
-    *ms_per_interval = n->prof_empty_ms < 0 ? 0.0 : n->prof_empty_ms;
+    *ms_per_interval = n->prof_empty_ms;
     return AZ_OK;
 }
 
 extern "C" int az_net_profile_read(az_net *n, double *ms_total, int64_t *launches) {
     AZ_REQUIRE(n && ms_total && launches, AZ_EINVAL, "null argument");
     AZ_TRY(prof_harvest(n));
-    for (int i = 0; i < 5; ++i) { ms_total[i] = n->prof_ms[i]; launches[i] = n->prof_n[i]; }
+    for (int i = 0; i < 8; ++i) { ms_total[i] = n->prof_ms[i]; launches[i] = n->prof_n[i]; }
     return AZ_OK;
 }
 
@@ -3290,15 +3307,21 @@ static int forward_impl(az_net *n, const float *d_input, int B, const int *dyn, 
         for (int s = 0; s < 4; ++s) AZ_TRY(run_stage(n, s, d_input, B, dyn, d_probs, d_value, st));
         return AZ_OK;
     }
-    if (n->prof_empty_ms < 0) AZ_TRY(prof_calibrate(n, st));
     if (n->prof_used == PROF_SLOTS) AZ_TRY(prof_harvest(n));
-    hipEvent_t *ev = n->prof_ev.data() + (size_t)n->prof_used * 5;
-    AZ_HIP(hipEventRecord(ev[0], st));
-    for (int s = 0; s < 4; ++s) {
-        AZ_TRY(run_stage(n, s, d_input, B, dyn, d_probs, d_value, st));
-        AZ_HIP(hipEventRecord(ev[s + 1], st));
+    hipEvent_t *ev = n->prof_ev.data() + (size_t)n->prof_used * 8;
+    int kind = 0, has = 0, rc = AZ_OK;
+    for (int s = 0; s < 4 && rc == AZ_OK; ++s) {
+        g_last_gemm_small = 0;
+        g_ev_start = ev[2 * s]; g_ev_stop = ev[2 * s + 1]; g_ev_used = 0;
+        rc = run_stage(n, s, d_input, B, dyn, d_probs, d_value, st);
+        g_ev_start = g_ev_stop = nullptr;
+        if (g_ev_used) has |= 1 << s;
+        if (s == 0) kind |= n->last_trunk_two_boards ? 1 : (n->last_trunk_q ? 2 : 0);
+        if ((s == 1 || s == 2) && g_last_gemm_small) kind |= s == 1 ? 4 : 8;
     }
-    n->prof_kind[n->prof_used++] = n->last_trunk_two_boards;
+    AZ_TRY(rc);
+    n->prof_has[n->prof_used] = has;
+    n->prof_kind[n->prof_used++] = kind;
     return AZ_OK;
 }
 

@@ -173,13 +173,13 @@ class HipNet:
 
     def profile_read(self):
         """-> {kernel: (total ms, launches)} since profile(True)"""
-        ms, n = (C.c_double * 5)(), (C.c_int64 * 5)()
+        ms, n = (C.c_double * 8)(), (C.c_int64 * 8)()
         check(lib().az_net_profile_read(self.h, ms, n))
-        names = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads", "k_trunk"]
-        return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+        return {k: (ms[i], n[i]) for i, k in enumerate(PROFILE_SLOTS)}
 
     def profile_overhead_ms(self):
-        """what one event-to-event interval costs without a kernel in it (subtract per launch from profile_read totals)"""
+        """correction to subtract per launch from profile_read totals: 0 since every launch carries its own start / stop events
+        (rounds 1-3 recorded events between the launches and calibrated an empty interval)"""
         ms = C.c_double()
         check(lib().az_net_profile_overhead(self.h, C.byref(ms)))
         return float(ms.value)
@@ -194,6 +194,10 @@ class HipNet:
             self.close()
         except Exception:  # interpreter shutdown: module globals may already be gone
             pass
+
+
+# az_net_profile_read's slots: one per kernel family (a slot's mean is what rocprofv3 lists for that kernel)
+PROFILE_SLOTS = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads", "k_trunk", "small fc1", "small fc2", "k_trunk_q"]
 
 
 # ---------------------------------------------------------------------------------------------- engine

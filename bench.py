@@ -11,7 +11,7 @@ from the start position to the end at 100 MCTS simulations per move through the 
 torch.manual_seed(0), Dirichlet noise 0.03/0.25, tau linear(4,4), tree reuse) and, for N > 1, all-gathers the samples over RCCL.
 value = games of all ranks / time; K steps = K waves (">= 2 waves, steady-state rate").  The timed region runs the engine as
 it ships (searches replayed as HIP graphs, no event recording); the per-kernel times of the roofline come from one extra, separately
-profiled step.
+profiled step in which every network launch carries its own start / stop events (the dispatch's begin / end timestamps).
 
 The driver's record keeps the scalar fields of `config`, `roofline` and `cpu_baseline` (nested objects and long strings are cut), so
 everything that has to survive there is a FLAT scalar inside `config` / `roofline`:
@@ -29,7 +29,9 @@ How to read `roofline` (every field can be recomputed from profiles/ + the field
                     trunk: the FLOPs the kernel ISSUES (conv2 in the Winograd form issues fewer multiplications than the direct
                     form) -- the direct-form figure is in frac_algorithmic_direct_form
   frac              achieved / peak (157.3 TFLOP/s, f32-input MFMA): how busy the matrix pipe is, never above 1
-  avg_launch_ms     kernel_ms_total / launches: what rocprofv3 --stats lists as the kernel's average duration
+  avg_launch_ms     time / launches of the kernel the stage is named after (k_gemm, k_trunk2, ...): what rocprofv3 --stats lists as that
+                    kernel's average duration; the last plies of a wave run on the small-batch kernels (k_dense_frag, k_trunk, k_trunk_q),
+                    whose time is in kernel_ms_total (all boards went through one or the other) and whose launches are booked apart
   forward_frac      all four stages: algorithmic FLOPs of a forward x boards / network time / peak
   end_to_end_frac   boards the TIMED region evaluated x algorithmic FLOPs of a forward / timed seconds / peak (per GPU)
   traffic, mfma_busy  PMC figures of one full-batch launch (profiles/traffic.json, mfma_counters.json), used only when the files'
@@ -61,7 +63,8 @@ def _imports():
 
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
-SLOTS = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads", "k_trunk"]  # az_net_profile_read's five counters
+# az_net_profile_read's counters, one per kernel family (the small-batch kernels serve the last plies of a wave, when few games are left)
+SLOTS = ["k_trunk2", "k_gemm fc1", "k_gemm fc2", "k_heads", "k_trunk", "small fc1", "small fc2", "k_trunk_q"]
 # the Python reference and the C oracle on ONE core of the build container (Xeon @ 2.10 GHz, 8 vCPU): BASELINE.md section 2
 # (8.38 s per Othello 8x8 game at 100 sims) and `python oracle/selfplay_worker.py` there (4 games: 6.33 +- 0.73 s per game)
 REF_S_PER_GAME_BUILD_CONTAINER = 8.38
@@ -333,7 +336,7 @@ class Workload:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         prof = self.hnet.profile_read()
-        ov = self.hnet.profile_overhead_ms()  # an event-to-event interval costs this much with no kernel in it
+        ov = self.hnet.profile_overhead_ms()  # 0 since round 4: every launch carries its own start / stop events (dispatch begin / end)
         self.hnet.profile(False)
         fl, by = stage_flops(*self.geom), algorithmic_bytes(*self.geom)
         fused_tail = self.game == "connect4"  # fc1 + fc2 + heads are one fused launch (k_tail_mfma), booked in the fc1 slot
@@ -344,10 +347,14 @@ class Workload:
         exe, wino = executed_conv_flops(*self.geom[:2])
         # the kernels of a forward.  fc1 and fc2 are two launches of ONE kernel; the trunk's few small-batch launches (k_trunk, end of a
         # wave) are booked with k_trunk2: their boards are in `evals` too
+        # `ms`: all launches of the stage (every board of `evals` went through one of them); `own_ms` / `launches`: the launches of the
+        # kernel the stage is NAMED after -- their mean is the average duration rocprofv3 --stats lists for that kernel.  The few
+        # launches of a wave's last plies run on the small-batch kernels (k_trunk / k_trunk_q, k_dense_frag) and are booked apart
         kern = {
-            "trunk": {"name": self.hnet.stage_kernel(0, self.G), "ms": ms["k_trunk2"] + ms["k_trunk"], "launches": cnt["k_trunk2"],
+            "trunk": {"name": self.hnet.stage_kernel(0, self.G), "ms": ms["k_trunk2"] + ms["k_trunk"] + ms["k_trunk_q"], "launches": cnt["k_trunk2"],
                       "own_ms": ms["k_trunk2"], "flops": exe, "flops_algorithmic": fl[0], "bytes": by[0], "pmc": ["k_trunk"]},
-            "dense": {"name": self.hnet.stage_kernel(1, self.G), "ms": ms["k_gemm fc1"] + ms["k_gemm fc2"], "launches": cnt["k_gemm fc1"] + cnt["k_gemm fc2"],
+            "dense": {"name": self.hnet.stage_kernel(1, self.G), "ms": ms["k_gemm fc1"] + ms["k_gemm fc2"] + ms["small fc1"] + ms["small fc2"],
+                      "launches": cnt["k_gemm fc1"] + cnt["k_gemm fc2"],
                       "own_ms": ms["k_gemm fc1"] + ms["k_gemm fc2"], "flops": fl[1] + fl[2] + (fl[3] if fused_tail else 0),
                       "flops_algorithmic": fl[1] + fl[2] + (fl[3] if fused_tail else 0), "bytes": by[1] + by[2], "pmc": ["k_gemm_fc1", "k_gemm_fc2"] if not fused_tail else ["k_tail"]},
             "heads": {"name": self.hnet.stage_kernel(3, self.G), "ms": ms["k_heads"], "launches": cnt["k_heads"], "own_ms": ms["k_heads"],
@@ -373,14 +380,16 @@ class Workload:
         roof = {"bound": "mfma", "kernel": K["name"] + (" (fc1 + fc2: two launches per forward)" if dom == "dense" and not fused_tail else ""),
                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                 "flops_per_board": K["flops"], "boards_evaluated": evals, "kernel_ms_total": K["ms"], "launches": K["launches"],
-                "avg_launch_ms": K["own_ms"] / max(1, K["launches"]), "avg_boards_per_launch": evals / max(1, cnt["k_trunk2"] + cnt["k_trunk"]),
+                "avg_launch_ms": K["own_ms"] / max(1, K["launches"]),
+                "avg_boards_per_launch": evals / max(1, cnt["k_trunk2"] + cnt["k_trunk"] + cnt["k_trunk_q"]),
+                "small_batch_launches": {k: cnt[k] for k in ("k_trunk", "k_trunk_q", "small fc1", "small fc2")},
                 "share_of_network_time": K["ms"] / net_ms,
                 "traffic": traffic, "traffic_algorithmic": self.G * K["bytes"], "traffic_source": twhy,
                 "traffic_is_for": f"one launch of every stage of the kernel at the full batch of {self.G} boards (tools/prof_net.py under rocprofv3 --pmc)",
                 "mfma_busy": busy, "mfma_busy_source": cwhy,
                 "event_overhead_ms_per_interval": ov,
-                "measured_on": "one separately profiled step after the timed region: HIP events on the engine's stream around every launch, "
-                               "minus the calibrated cost of an empty event interval per launch",
+                "measured_on": "one separately profiled step after the timed region: every network launch carries a start and a stop event "
+                               "(hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, what rocprofv3 reports)",
                 "profiled_step_ms": 1e3 * dt,
                 "kernels": {k: {"name": v["name"], "ms": v["ms"], "launches": v["launches"], "flops_per_board": v["flops"],
                                 "tflops": v["flops"] * evals / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None,
@@ -393,7 +402,7 @@ class Workload:
                 "network_share_of_profiled_step": sum(raw.values()) / (1e3 * dt)}
         if dom == "trunk":
             roof["conv2_form"] = "Winograd F(2x2,3x3)" if wino else "direct"
-            roof["small_batch_trunk_launches"] = cnt["k_trunk"]
+            roof["small_batch_trunk_launches"] = cnt["k_trunk"] + cnt["k_trunk_q"]
             roof["frac_algorithmic_direct_form"] = fl[0] * evals / (K["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
             roof["flops_per_board_direct_form"] = fl[0]
         if timed_evals is not None and timed_seconds:

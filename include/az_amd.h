@@ -101,13 +101,16 @@ int az_net_time_stage(az_net *net, int stage, int B, int iters, void *stream, fl
 /* name of the kernel that stage (0..3) launches for a batch of B boards, as rocprofv3 lists it (template arguments abbreviated) */
 int az_net_stage_kernel(const az_net *net, int stage, int B, char *buf, int cap);
 /* Live measurement (the idiom of timers.py:53-76 applied per kernel): while enabled, every forward brackets its stage
- * launches with HIP events on its own stream.  ms_total[5] / launches[5]: k_trunk2, k_gemm fc1, k_gemm fc2, k_heads,
- * k_trunk (one board per wave, small batches). */
+ * launches with a start and a stop event each (hipExtLaunchKernelGGL).  ms_total[8] / launches[8], one slot per kernel family so that a slot's mean is the
+ * figure rocprofv3 lists for that kernel: k_trunk2, fc1 and fc2 on the tiled GEMMs (k_gemm / k_gemm_solo; Connect4Net's fused tail
+ * in the fc1 slot), k_heads, k_trunk (one board per wave) | fc1, fc2 on the small-batch kernels (k_dense_frag / k_dense_small),
+ * k_trunk_q. */
 int az_net_profile(az_net *net, int enable);
 int az_net_profiling(const az_net *net); /* 1 while enabled (the engine then launches kernel by kernel instead of replaying graphs) */
 int az_net_profile_read(az_net *net, double *ms_total, int64_t *launches);
-/* cost of one event-to-event interval with no kernel in it (calibrated when profiling first runs): subtract it per launch
- * from ms_total to compare with rocprofv3's kernel durations */
+/* correction to subtract per launch from ms_total before comparing with rocprofv3's kernel durations: 0 -- every profiled launch
+ * carries its own start / stop events (the dispatch's begin / end timestamps); kept for callers written against rounds 1-3, which
+ * recorded events BETWEEN the launches and calibrated the cost of an empty interval */
 int az_net_profile_overhead(az_net *net, double *ms_per_interval);
 
 /* ---- self-play engine (K3/K4/K7/K8/K9) -------------------------------------------------------
