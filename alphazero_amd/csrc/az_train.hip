@@ -262,14 +262,16 @@ __global__ __launch_bounds__(TPB) void k_conv1_fwd(TDims d, TPtr q) {
     if (t < 32) bl[t] = q.p.cb[0][t];
     for (int i = t; i < 100; i += TPB) xin[i] = 0.0f;
     double n = 0.0, mean = 0.0, M2 = 0.0;
+    // the board's row (permutation -> sample row -> 64 int8 cells: two dependent trips) is fetched one board ahead
+    float xv = 0.0f;
+    if ((int)blockIdx.x < d.B && t < d.P1) xv = (float)q.state[sample_row(q.perm, hp.perm_off + blockIdx.x, hp, q.hp) * d.P1 + t];
     __syncthreads();
     for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
-        const long long row = sample_row(q.perm, hp.perm_off + b, hp, q.hp);
-        for (int p = t; p < d.P1; p += TPB) {
-            const float v = (float)q.state[row * d.P1 + p];
-            xin[(p / d.CW + 1) * WP + p % d.CW + 1] = v;
-            q.x0[b * d.P1 + p] = v;
+        if (t < d.P1) {
+            xin[(t / d.CW + 1) * WP + t % d.CW + 1] = xv;
+            q.x0[b * d.P1 + t] = xv;
         }
+        if (b + (int)gridDim.x < d.B && t < d.P1) xv = (float)q.state[sample_row(q.perm, hp.perm_off + b + gridDim.x, hp, q.hp) * d.P1 + t];
         __syncthreads();
         for (int i = t; i < d.P1 * 32; i += TPB) {
             const int p = i >> 5, oc = i & 31, r = p / d.CW, c = p % d.CW;
@@ -1125,13 +1127,16 @@ static inline int fc_wgrad_blocks(int N, int K, int NW) { return ((N / 32) * (K 
 // The same tile with its K (the batch rows) split over FOUR waves: wave (tile, ks) multiplies rows [ks B/4, (ks+1) B/4), the four
 // partial tiles meet in LDS (part[wave][32 x 32]) and wave ks = 0 adds them in order and updates.  At batch 512 one wave walking all
 // rows is sixteen dependent trips of eight MFMA steps; a quarter each is four.  Every wave of the workgroup must call (one barrier).
-AZ_D void fc_wgrad_tile_ks(const TDims &d, const TPtr &q, const Hyper &hp, int layer, int tile, int ks, float *part) {
+AZ_D void fc_wgrad_tile_ks(const TDims &d, const TPtr &q, const Hyper &hp, int layer, int tile, int ks, float *part, const float *s_scale = nullptr,
+                           const float *s_shift = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n16 = lane & 15, kq = lane >> 4;
     const int N = layer == 1 ? d.F1 : d.F2, K = layer == 1 ? d.FIN : d.F1, TK = K / 32;
     const bool live = tile < (N / 32) * TK;
     const int j0 = 32 * (tile / TK), k0 = 32 * (tile % TK);
     const float *dZ = layer == 1 ? q.dz1 : q.dz2, *X = layer == 1 ? q.c[3] : q.h1;
     float *W = layer == 1 ? q.p.w1 : q.p.w2, *M = layer == 1 ? q.m.w1 : q.m.w2;
+    float sc0 = 1.f, sh0 = 0.f, sc1 = 1.f, sh1 = 0.f;  // layer 1: X = relu(bn4(c4)) formed on load; k0 is a multiple of 32: channel = 16 nt + n16
+    if (layer == 1) { sc0 = s_scale[n16]; sh0 = s_shift[n16]; sc1 = s_scale[16 + n16]; sh1 = s_shift[16 + n16]; }
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1159,8 +1164,10 @@ AZ_D void fc_wgrad_tile_ks(const TDims &d, const TPtr &q, const Hyper &hp, int l
 #pragma unroll
             for (int p = 0; p < 8; ++p)
                 if (b0 + 4 * p < bend) {
-                    acc[0][0] = MFMA(a0[p], x0[p], acc[0][0]); acc[0][1] = MFMA(a0[p], x1[p], acc[0][1]);
-                    acc[1][0] = MFMA(a1[p], x0[p], acc[1][0]); acc[1][1] = MFMA(a1[p], x1[p], acc[1][1]);
+                    float u0 = x0[p], u1 = x1[p];
+                    if (layer == 1) { u0 = fmaxf(fmaf(u0, sc0, sh0), 0.f); u1 = fmaxf(fmaf(u1, sc1, sh1), 0.f); }
+                    acc[0][0] = MFMA(a0[p], u0, acc[0][0]); acc[0][1] = MFMA(a0[p], u1, acc[0][1]);
+                    acc[1][0] = MFMA(a1[p], u0, acc[1][0]); acc[1][1] = MFMA(a1[p], u1, acc[1][1]);
                 }
         }
 #pragma unroll
@@ -1456,7 +1463,21 @@ __global__ __launch_bounds__(TPB) void k_mix2(TDims d, TPtr q, int nw) {
 // ---------------------------------------------------------------------------------------------------------------- conv1 backward
 // dW1[tap][oc] = sum over boards and positions of x0[p + tap - 1] dz1[p][oc] (VALU: K = 9 taps x 1 input channel); thread i owns
 // element i (and, for i < 32, element 256 + i) of the 288 + 32 partial
+// Row-split path (batch > 128): the workgroups behind the first NB are fc1's weight-gradient tiles (one 32 x 32 tile each, K = the batch
+// rows split over the four waves).  In k_mix2 they share a launch with conv4's backward, whose 107 KB of LDS allow ONE workgroup per CU:
+// 128 tile workgroups of sixteen dependent trips queued with 256 board workgroups for 1.5 rounds; here they need 23 KB and run beside
+// the conv1 workgroups.  (W1 was last read by k_mix1's data gradient and is next read by the following step's forward.)
+#define CONV1_WG_LDS_BYTES (4 * 1024 * 4 + 4 * 32 * 4 + 768 * 8)
 __global__ __launch_bounds__(TPB) void k_conv1_bwd(TDims d, TPtr q) {
+    if ((int)blockIdx.x >= d.NB) {
+        extern __shared__ __align__(16) float wg_lds[];
+        float *part = wg_lds, *s_scale = part + 4 * 1024, *s_shift = s_scale + 32, *s_mean = s_shift + 32, *s_inv = s_mean + 32;
+        double *wscr = (double *)(s_inv + 32);
+        const Hyper hp = *q.hp;
+        bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, wscr);
+        fc_wgrad_tile_ks(d, q, hp, 1, (int)blockIdx.x - d.NB, threadIdx.x >> 6, part, s_scale, s_shift);
+        return;
+    }
     __shared__ float xin[10 * 10];
     __shared__ float dzl[64 * LDP];
     __shared__ float k1[32], sh_o[32], mean_o[32], inv_o[32], k2[32], k3[32];
@@ -1464,10 +1485,23 @@ __global__ __launch_bounds__(TPB) void k_conv1_bwd(TDims d, TPtr q) {
     __shared__ double scr[768];
     const int t = threadIdx.x, ch = t & 31, grp = t >> 5, WP = d.CW + 2, P1 = d.P1;
     if (blockIdx.x == 0) TBEG(15);
+    // a board's planes travel through registers: the first board's loads go out before the statistics are combined, the next board's
+    // while this one is being multiplied (<= 64 positions x 32 channels / 256 threads = 8 values per plane and thread)
+    float r_c[8], r_dy[8], r_x = 0.0f;
+    auto fetch = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = t + TPB * k;
+            if (i < P1 * 32) { r_c[k] = q.c[0][(size_t)b * P1 * 32 + i]; r_dy[k] = q.dy[0][(size_t)b * P1 * 32 + i]; }
+        }
+        if (t < P1) r_x = q.x0[(size_t)b * P1 + t];
+    };
+    if ((int)blockIdx.x < d.B) fetch(blockIdx.x);
     if (t < P1) poff[t] = (t / d.CW) * WP + t % d.CW;
     bn2d_prepare(d, q, 0, k1, sh_o, mean_o, inv_o, scr);
     {
         double S1 = 0.0, S2 = 0.0;
+#pragma unroll 8
         for (int p = grp; p < d.NB; p += 8) { S1 += q.bpart[0][(size_t)p * 64 + ch]; S2 += q.bpart[0][(size_t)p * 64 + 32 + ch]; }
         scr[grp * 32 + ch] = S1; scr[256 + grp * 32 + ch] = S2;
         __syncthreads();
@@ -1482,13 +1516,17 @@ __global__ __launch_bounds__(TPB) void k_conv1_bwd(TDims d, TPtr q) {
     __syncthreads();
     float g0 = 0.0f, g1 = 0.0f;  // element t (tap = t >> 5, oc = t & 31) and element 256 + t (tap 8) / bias (t < 32: 288 + t handled by g1b)
     float gb = 0.0f;
-    for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
-        for (int p = t; p < P1; p += TPB) xin[(p / d.CW + 1) * WP + p % d.CW + 1] = q.x0[(size_t)b * P1 + p];
-        for (int i = t; i < P1 * 32; i += TPB) {
-            const int oc = i & 31;
-            const float xo = (q.c[0][(size_t)b * P1 * 32 + i] - mean_o[oc]) * inv_o[oc];
-            dzl[(i >> 5) * LDP + oc] = k1[oc] * ((q.dy[0][(size_t)b * P1 * 32 + i] - k2[oc]) - xo * k3[oc]);
+    for (int b = blockIdx.x; b < d.B; b += d.NB) {
+        if (t < P1) xin[(t / d.CW + 1) * WP + t % d.CW + 1] = r_x;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = t + TPB * k, oc = i & 31;
+            if (i < P1 * 32) {
+                const float xo = (r_c[k] - mean_o[oc]) * inv_o[oc];
+                dzl[(i >> 5) * LDP + oc] = k1[oc] * ((r_dy[k] - k2[oc]) - xo * k3[oc]);
+            }
         }
+        if (b + d.NB < d.B) fetch(b + d.NB);
         __syncthreads();
         {
             const int tap = t >> 5, oc = t & 31;  // taps 0..7
@@ -2074,6 +2112,18 @@ extern "C" int az_trainer_set_lr(az_trainer *t, float lr, void *stream) {
     return t_leave(t, user);
 }
 
+static bool wgrad_beside_conv1() {  // AZ_TRAIN_WG_LATE=0: fc1's weight gradient stays in k_mix2 on the row-split path too
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("AZ_TRAIN_WG_LATE"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v == 1;
+}
+
+static bool fc2_rows64() {  // AZ_TRAIN_FC2_RB64=0: fc2's forward keeps the step's row-block size
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("AZ_TRAIN_FC2_RB64"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v == 1;
+}
+
 template <int RTM, int NW, int PF, int NT, bool SPLIT>
 static int enqueue_step_t(az_trainer *t) {
     const TDims &d = t->d;
@@ -2093,13 +2143,24 @@ static int enqueue_step_t(az_trainer *t) {
         SETATTR((k_heads_bwd<RTM, NT, SPLIT>), RTM * 16 * 16 * 4 + 768 * 8);
     }
 #undef SETATTR
+#define SETATTR2(k, bytes) AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)))
     const dim3 tb(TPB), tw(NW * 64);
     hipLaunchKernelGGL(k_conv1_fwd, dim3(d.NB), tb, 0, st, d, q);
     for (int l = 1; l <= 3; ++l) hipLaunchKernelGGL(k_conv_fwd, dim3(d.NB), tb, CONV_FWD_LDS_BYTES, st, d, q, l);
     hipLaunchKernelGGL((k_fc_fwd<RTM, NW, PF, SPLIT>), dim3(d.F1 / 16, NRB), tw, fcl, st, d, q, 1);
     if (SPLIT) hipLaunchKernelGGL(k_fc_fin, dim3(d.F1 / 16, NRB), tb, 0, st, d, q, 1);
-    hipLaunchKernelGGL((k_fc_fwd<RTM, NW, PF, SPLIT>), dim3(d.F2 / 16, NRB), tw, fcl, st, d, q, 2);
-    if (SPLIT) hipLaunchKernelGGL(k_fc_fin, dim3(d.F2 / 16, NRB), tb, 0, st, d, q, 2);
+    if (SPLIT && RTM == 8 && fc2_rows64()) {
+        // fc2 has half of fc1's columns: at 128 rows per block its forward would run 32 x NRB = 128 workgroups on 256 CUs.  It takes the
+        // 64-row configuration (sixteen waves split K = 1024) instead; its statistics partials and its finalize kernel follow that block size
+        TDims d2 = d;
+        d2.RB = 64; d2.NRB = (d.B + 63) / 64;
+        SETATTR2((k_fc_fwd<4, 16, 1, true>), fc_lds_bytes(16, 64));
+        hipLaunchKernelGGL((k_fc_fwd<4, 16, 1, true>), dim3(d.F2 / 16, (unsigned)d2.NRB), dim3(16 * 64), fc_lds_bytes(16, 64), st, d2, q, 2);
+        hipLaunchKernelGGL(k_fc_fin, dim3(d.F2 / 16, (unsigned)d2.NRB), tb, 0, st, d2, q, 2);
+    } else {
+        hipLaunchKernelGGL((k_fc_fwd<RTM, NW, PF, SPLIT>), dim3(d.F2 / 16, NRB), tw, fcl, st, d, q, 2);
+        if (SPLIT) hipLaunchKernelGGL(k_fc_fin, dim3(d.F2 / 16, NRB), tb, 0, st, d, q, 2);
+    }
     hipLaunchKernelGGL((k_heads_fwd<NT, 8>), dim3(d.B / 16), dim3(8 * 64), 0, st, d, q);
     hipLaunchKernelGGL((k_heads_bwd<RTM, NT, SPLIT>), dim3(d.F2 / 16, NRB), tb, hbl, st, d, q);
     if (SPLIT) hipLaunchKernelGGL(k_bn1d_bwd_fin, dim3(d.F2 / 16, NRB), tb, 0, st, d, q, 2);
@@ -2107,10 +2168,13 @@ static int enqueue_step_t(az_trainer *t) {
     if (SPLIT) hipLaunchKernelGGL(k_bn1d_bwd_fin, dim3(d.F1 / 16, NRB), tb, 0, st, d, q, 1);
     const int nw2 = fc_wgrad_blocks(d.F2, d.F1, SPLIT ? NW / 4 : NW), nw1 = fc_wgrad_blocks(d.F1, d.FIN, 4);
     hipLaunchKernelGGL((k_mix1<RTM, NW, PF, SPLIT>), dim3(nw2 + (d.FIN / 16) * NRB), tw, fcl, st, d, q, nw2);
-    hipLaunchKernelGGL(k_mix2, dim3(nw1 + d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, nw1);
+    const bool wg_late = SPLIT && wgrad_beside_conv1();  // fc1's weight gradient beside conv1's backward instead of conv4's
+    if (wg_late) hipLaunchKernelGGL(k_conv_bwd, dim3(d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, 3);
+    else hipLaunchKernelGGL(k_mix2, dim3(nw1 + d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, nw1);
     hipLaunchKernelGGL(k_conv_bwd, dim3(d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, 2);
     hipLaunchKernelGGL(k_conv_bwd, dim3(d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, 1);
-    hipLaunchKernelGGL(k_conv1_bwd, dim3(d.NB), tb, 0, st, d, q);
+    if (wg_late) hipLaunchKernelGGL(k_conv1_bwd, dim3(d.NB + (d.F1 / 32) * (d.FIN / 32)), tb, CONV1_WG_LDS_BYTES, st, d, q);
+    else hipLaunchKernelGGL(k_conv1_bwd, dim3(d.NB), tb, 0, st, d, q);
     hipLaunchKernelGGL(k_update, dim3((UPD_ALL + 63) / 64 + 4), tb, 0, st, d, q);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
