@@ -114,6 +114,9 @@ struct TPtr {
     double *colsum;     // backward sums of bn4 per fc1 input column and row block: [NRB][FIN][2]
     double *fstat[2];   // row-split dense forward: (n, mean, M2) of y per (row block, column): [NRBMAX][N][3]
     double *bstat[2];   // row-split BatchNorm1d backward: (sum dy, sum dy xhat, sum xhat) per (row block, column): [NRBMAX][N][3]
+    float *fdone[4];    // finished forward statistics of BatchNorm2d l: mean[32] inv[32] scale[32] shift[32] var[32], written once per step by
+                        // workgroup 0 of the first kernel that combines the layer's partials (conv_fwd l + 1; fc1's forward for l = 3);
+                        // the backward kernels and k_update read these 160 floats instead of walking NB partials again
     float *hwpart;      // row-split heads backward: the row block's share of d Wh [NRBMAX][NHP][F2], then of d bh [NRBMAX][NHP]
     float *gw[4];       // weight-gradient partials [NB][9*32*32 + 32] (conv1: [NB][9*32 + 32]): weights then bias
 };
@@ -177,7 +180,8 @@ AZ_D void bsum_walk(const TDims &d, const TPtr &q, int l, double &S1, double &S2
     }
 }
 // finish a forward statistic from the eight group sums at scr[g * 32 * W + ch * W + o .. o + 2]: mean, 1 / sqrt(var + eps), scale, shift
-AZ_D void fpart_finish(const TDims &d, const TPtr &q, int l, const double *scr, int W, int o, float *s_scale, float *s_shift, float *s_mean, float *s_inv) {
+AZ_D void fpart_finish(const TDims &d, const TPtr &q, int l, const double *scr, int W, int o, float *s_scale, float *s_shift, float *s_mean, float *s_inv,
+                       float *done = nullptr) {
     const int ch = threadIdx.x;
     double N = 0.0, S = 0.0, Q = 0.0;
 #pragma unroll
@@ -188,17 +192,30 @@ AZ_D void fpart_finish(const TDims &d, const TPtr &q, int l, const double *scr, 
     const float inv = (float)(1.0 / sqrt(M2 / N + BN_EPS));
     const float sc = q.p.bg[l][ch] * inv;
     s_mean[ch] = (float)mean; s_inv[ch] = inv; s_scale[ch] = sc; s_shift[ch] = q.p.bb[l][ch] - (float)mean * sc;
+    if (done) { done[ch] = s_mean[ch]; done[32 + ch] = inv; done[64 + ch] = sc; done[96 + ch] = s_shift[ch]; done[128 + ch] = (float)(M2 / N); }
+}
+// the finished statistics of layer l as the first combining kernel left them (threads 0..31 call)
+AZ_D void fdone_load(const float *done, float *s_scale, float *s_shift, float *s_mean, float *s_inv) {
+    const int ch = threadIdx.x;
+    s_mean[ch] = done[ch]; s_inv[ch] = done[32 + ch]; s_scale[ch] = done[64 + ch]; s_shift[ch] = done[96 + ch];
 }
 
 // scale / shift of train-mode BatchNorm2d l (0..3) from its forward partials; also mean / 1/sqrt(var + eps)
-AZ_D void bn2d_prepare(const TDims &d, const TPtr &q, int l, float *s_scale, float *s_shift, float *s_mean, float *s_inv, double *scr) {
+AZ_D void bn2d_prepare(const TDims &d, const TPtr &q, int l, float *s_scale, float *s_shift, float *s_mean, float *s_inv, double *scr, float *done = nullptr) {
     bn2d_combine(q.fpart[l], d.NB, s_mean, s_inv, scr);
     if (threadIdx.x < 32) {
         const int ch = threadIdx.x;
-        const float inv = (float)(1.0 / sqrt((double)s_inv[ch] + BN_EPS));
+        const float var = s_inv[ch];
+        const float inv = (float)(1.0 / sqrt((double)var + BN_EPS));
         const float sc = q.p.bg[l][ch] * inv;
         s_inv[ch] = inv; s_scale[ch] = sc; s_shift[ch] = q.p.bb[l][ch] - s_mean[ch] * sc;
+        if (done) { done[ch] = s_mean[ch]; done[32 + ch] = inv; done[64 + ch] = sc; done[96 + ch] = s_shift[ch]; done[128 + ch] = var; }
     }
+    __syncthreads();
+}
+// the same from the record the first combining kernel of the step left (no walk over the partials): all threads call
+AZ_D void bn2d_from_done(const float *done, float *s_scale, float *s_shift, float *s_mean, float *s_inv) {
+    if (threadIdx.x < 32) fdone_load(done, s_scale, s_shift, s_mean, s_inv);
     __syncthreads();
 }
 
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(TPB) void k_conv_fwd(TDims d, TPtr q, int l /* 1..3
     if (t < Pin) pio[t] = ((t / Win + pad) * WP + t % Win + pad) * LDP;
     TSTAMP(1, 1);
     __syncthreads();
-    if (t < 32) fpart_finish(d, q, l - 1, scr, 3, 0, s_scale, s_shift, s_mean, s_inv);
+    if (t < 32) fpart_finish(d, q, l - 1, scr, 3, 0, s_scale, s_shift, s_mean, s_inv, blockIdx.x == 0 ? q.fdone[l - 1] : nullptr);
     __syncthreads();
     TSTAMP(1, 2);
     double n = 0.0, mean = 0.0, M2 = 0.0;
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_fwd(TDims d, TPtr q, int layer) 
     for (int i = 0; i < RTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (layer == 1)
         nt_kloop<RTM, PF, true>(acc, A, K, W + (size_t)(n0 + n16) * K, RT, kbeg, kend, n16, kq, s_scale, s_shift,
-                                [&] { bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr); });
+                                [&] { bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr, (blockIdx.x == 0 && rb == 0) ? q.fdone[3] : nullptr); });
     else nt_kloop<RTM, PF, false>(acc, A, K, W + (size_t)(n0 + n16) * K, RT, kbeg, kend, n16, kq, nullptr, nullptr, [] {});
     TSTAMP(2, 1);
     reduce_waves<RTM, NW>(acc, red, B, RT, wave, n16, kq);
@@ -1223,7 +1240,7 @@ __global__ __launch_bounds__(NW * 64) void k_mix1(TDims d, TPtr q, int nw) {
 #pragma unroll
     for (int i = 0; i < RTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     nn_kloop<RTM, PF>(acc, q.dz1 + (size_t)r0 * J, J, q.p.w1 + k0, FIN, RT, jbeg, jend, n16, kq,
-                      [&] { bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr); });  // the statistics are combined under the first loads
+                      [&] { bn2d_from_done(q.fdone[3], s_scale, s_shift, s_mean, s_inv); });  // conv4's finished statistics arrive under the first loads
     reduce_waves<RTM, NW>(acc, red, B, RT, wave, n16, kq);
     const int col = t & 15, rg = (t >> 4) & 15, k = k0 + col, ch = k & 31;
     double s1 = 0.0, s2 = 0.0;
@@ -1282,14 +1299,14 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
     float4 wreg[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) wreg[i] = *(const float4 *)(q.p.cw[l] + (i * TPB + t) * 4);
-    {   // the three statistics this kernel needs, walked together: BatchNorm l (forward) and its backward sums, BatchNorm l - 1 (forward)
-        double a0, a1, a2, b0, b1, c0, c1, c2;
-        fpart_walk(q.fpart[l], d.NB, a0, a1, a2);
+    {   // the backward sums of BatchNorm l are fresh partials and are walked here; the two FORWARD statistics this kernel needs (layers l
+        // and l - 1) were finished by the forward pass: 2 x 128 floats from q.fdone instead of two more walks over NB partials
+        double b0, b1;
         bsum_walk(d, q, l, b0, b1);
-        fpart_walk(q.fpart[l - 1], d.NB, c0, c1, c2);
         double *o = scr + (size_t)(grp * 32 + ch) * 8;
-        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = c0; o[6] = c1; o[7] = c2;
+        o[3] = b0; o[4] = b1;
     }
+    if (t < 32) { fdone_load(q.fdone[l], k1, sh_o, mean_o, inv_o); fdone_load(q.fdone[l - 1], sc_i, sh_i, mean_i, inv_i); }  // k1 = gamma_l / sqrt(var_l + eps)
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int e = (i * TPB + t) * 4;
@@ -1301,8 +1318,6 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
     if (t < Pin) pio[t] = ((t / Win + pad) * WA + t % Win + pad) * LDP;
     __syncthreads();
     if (t < 32) {
-        fpart_finish(d, q, l, scr, 8, 0, k1, sh_o, mean_o, inv_o);      // k1 = gamma_l / sqrt(var_l + eps)
-        fpart_finish(d, q, l - 1, scr, 8, 5, sc_i, sh_i, mean_i, inv_i);
         double S1 = 0.0, S2 = 0.0;
 #pragma unroll
         for (int g = 0; g < 8; ++g) { S1 += scr[(g * 32 + ch) * 8 + 3]; S2 += scr[(g * 32 + ch) * 8 + 4]; }
@@ -1450,7 +1465,8 @@ __global__ __launch_bounds__(TPB) void k_mix2(TDims d, TPtr q, int nw) {
         float *s_scale = lds, *s_shift = s_scale + 32, *s_mean = s_shift + 32, *s_inv = s_mean + 32;
         double *scr = (double *)(s_inv + 32);
         const Hyper hp = *q.hp;
-        bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, scr);
+        bn2d_from_done(q.fdone[3], s_scale, s_shift, s_mean, s_inv);
+        (void)scr;
         fc_wgrad_tile<8>(d, q, hp, 1, blockIdx.x * 4 + (threadIdx.x >> 6), s_scale, s_shift);
         if (blockIdx.x == 0) TEND(11);
         return;
@@ -1474,7 +1490,8 @@ __global__ __launch_bounds__(TPB) void k_conv1_bwd(TDims d, TPtr q) {
         float *part = wg_lds, *s_scale = part + 4 * 1024, *s_shift = s_scale + 32, *s_mean = s_shift + 32, *s_inv = s_mean + 32;
         double *wscr = (double *)(s_inv + 32);
         const Hyper hp = *q.hp;
-        bn2d_prepare(d, q, 3, s_scale, s_shift, s_mean, s_inv, wscr);
+        bn2d_from_done(q.fdone[3], s_scale, s_shift, s_mean, s_inv);
+        (void)wscr;
         fc_wgrad_tile_ks(d, q, hp, 1, (int)blockIdx.x - d.NB, threadIdx.x >> 6, part, s_scale, s_shift);
         return;
     }
@@ -1498,7 +1515,7 @@ __global__ __launch_bounds__(TPB) void k_conv1_bwd(TDims d, TPtr q) {
     };
     if ((int)blockIdx.x < d.B) fetch(blockIdx.x);
     if (t < P1) poff[t] = (t / d.CW) * WP + t % d.CW;
-    bn2d_prepare(d, q, 0, k1, sh_o, mean_o, inv_o, scr);
+    bn2d_from_done(q.fdone[0], k1, sh_o, mean_o, inv_o);
     {
         double S1 = 0.0, S2 = 0.0;
 #pragma unroll 8
@@ -1567,7 +1584,7 @@ __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
     const int t = threadIdx.x;
     if (blockIdx.x >= gridDim.x - 4) {  // the last four workgroups: one BatchNorm2d layer's running statistics each (a walk over NB partials)
         const int l = (int)(gridDim.x - 1 - blockIdx.x);
-        bn2d_combine(q.fpart[l], d.NB, s_mean, s_var, scr);
+        if (t < 32) { s_mean[t] = q.fdone[l][t]; s_var[t] = q.fdone[l][128 + t]; }  // mean and biased variance as the forward pass finished them
         if (t < 32) {
             const double n = (double)d.B * plane_of(d, l);
             q.rm[l][t] = (float)((1.0 - BN_MOM) * q.rm[l][t] + BN_MOM * s_mean[t]);
@@ -1989,7 +2006,7 @@ extern "C" int az_trainer_create(int game, int H, int W, int max_batch, az_train
         for (int k = 0; k < 3 && rc == AZ_OK; ++k) { rc = talloc(t, pp[k], 32); if (rc == AZ_OK) rc = talloc(t, mm[k], 32); t->momenta.push_back({*mm[k], 32}); }
         TA(rm[l], 32); TA(rv[l], 32);
         const size_t P = l <= 1 ? d.P1 : (l == 2 ? d.P3 : d.P4);
-        TA(c[l], B * P * 32); TA(dy[l], B * P * 32); TA(fpart[l], NBmax * FPART);
+        TA(c[l], B * P * 32); TA(dy[l], B * P * 32); TA(fpart[l], NBmax * FPART); TA(fdone[l], 160);
         TA(gw[l], NBmax * (wn + 32));
         if (l < 3) TA(bpart[l], NBmax * 64);
     }
