@@ -769,17 +769,17 @@ __global__ __launch_bounds__(NW * 64) void k_heads_fwd(TDims d, TPtr q) {
     f32x4 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {  // two steps of 16 per trip: all loads first
-        float4 af[2], bf[2][NT];
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {  // four steps of 16 per trip, all loads first: a wave's whole chunk of OthelloNet's K = 512 is one trip
+        float4 af[4], bf[4][NT];
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < 4; ++p)
             if (k0 + 16 * p < kend) {
                 af[p] = *(const float4 *)(q.h2 + (size_t)(r0 + n16) * K + k0 + 16 * p + 4 * kq);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bf[p][nt] = *(const float4 *)(q.p.wh + (size_t)(16 * nt + n16) * K + k0 + 16 * p + 4 * kq);
             }
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < 4; ++p)
             if (k0 + 16 * p < kend)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
