@@ -11,4 +11,4 @@ void az_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *az_last_error(void) { return g_err; }
-extern "C" int az_version(void) { return 103; }  // 103: az_engine_search_begin / _end / _pair; 102: az_trainer_*, az_engine_nodes_used / grow_pools, az_net_stage_kernel
+extern "C" int az_version(void) { return 104; }  // 104: az_trainer_steps takes n_samples, az_trainer_check, az_net_profile_read has eight slots; 103: az_engine_search_begin / _end / _pair; 102: az_trainer_*, az_engine_nodes_used / grow_pools, az_net_stage_kernel
