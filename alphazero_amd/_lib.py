@@ -115,7 +115,7 @@ def lib():
 # the sources a measurement depends on: counter files of the network kernels stay valid while only the engine or the training step
 # changes, and the other way round
 CSRC_COMPONENTS = {"net": ("az_net.hip",), "engine": ("az_engine.hip",), "train": ("az_train.hip",)}
-_CSRC_SHARED = ("az_device.h", "az_host.h", "az_common.hip", "Makefile")
+_CSRC_SHARED = ("az_device.h", "az_host.h", "Makefile")  # az_common.hip (version number, error string) holds no kernel code
 
 
 def csrc_tree_hash(component=None):
