@@ -350,12 +350,15 @@ class Workload:
         # `ms`: all launches of the stage (every board of `evals` went through one of them); `own_ms` / `launches`: the launches of the
         # kernel the stage is NAMED after -- their mean is the average duration rocprofv3 --stats lists for that kernel.  The few
         # launches of a wave's last plies run on the small-batch kernels (k_trunk / k_trunk_q, k_dense_frag) and are booked apart
+        def own(*slots):  # the slot(s) of the kernel the stage is named after = whichever family served the full-size launches
+            return max(slots, key=lambda ks: sum(cnt[k] for k in ks))
+        t_own, d_own = own(("k_trunk2",), ("k_trunk",), ("k_trunk_q",)), own(("k_gemm fc1", "k_gemm fc2"), ("small fc1", "small fc2"))
         kern = {
-            "trunk": {"name": self.hnet.stage_kernel(0, self.G), "ms": ms["k_trunk2"] + ms["k_trunk"] + ms["k_trunk_q"], "launches": cnt["k_trunk2"],
-                      "own_ms": ms["k_trunk2"], "flops": exe, "flops_algorithmic": fl[0], "bytes": by[0], "pmc": ["k_trunk"]},
+            "trunk": {"name": self.hnet.stage_kernel(0, self.G), "ms": ms["k_trunk2"] + ms["k_trunk"] + ms["k_trunk_q"], "launches": sum(cnt[k] for k in t_own),
+                      "own_ms": sum(ms[k] for k in t_own), "flops": exe, "flops_algorithmic": fl[0], "bytes": by[0], "pmc": ["k_trunk"]},
             "dense": {"name": self.hnet.stage_kernel(1, self.G), "ms": ms["k_gemm fc1"] + ms["k_gemm fc2"] + ms["small fc1"] + ms["small fc2"],
-                      "launches": cnt["k_gemm fc1"] + cnt["k_gemm fc2"],
-                      "own_ms": ms["k_gemm fc1"] + ms["k_gemm fc2"], "flops": fl[1] + fl[2] + (fl[3] if fused_tail else 0),
+                      "launches": sum(cnt[k] for k in d_own),
+                      "own_ms": sum(ms[k] for k in d_own), "flops": fl[1] + fl[2] + (fl[3] if fused_tail else 0),
                       "flops_algorithmic": fl[1] + fl[2] + (fl[3] if fused_tail else 0), "bytes": by[1] + by[2], "pmc": ["k_gemm_fc1", "k_gemm_fc2"] if not fused_tail else ["k_tail"]},
             "heads": {"name": self.hnet.stage_kernel(3, self.G), "ms": ms["k_heads"], "launches": cnt["k_heads"], "own_ms": ms["k_heads"],
                       "flops": fl[3], "flops_algorithmic": fl[3], "bytes": by[3], "pmc": ["k_heads"]},
