@@ -140,7 +140,8 @@ class BatchedArena:
                  2: lambda: __import__("alphazero_amd.games.tictactoe", fromlist=["TicTacToeBoard"]).TicTacToeBoard()}[self.gid]()
         grids = np.tile(board.grid.astype(np.int8)[None], (G, 1, 1))
         ones = np.ones(G, np.int8)
-        ids = round_ids.astype(np.uint32) + np.uint32(self.seed * 100003)
+        # game id = (round + seed * 100003) mod 2^32: any seed is fine (np.uint32(big) raises, and uint32 + uint32 warns on wrap-around)
+        ids = ((round_ids.astype(np.uint64) + np.uint64((self.seed * 100003) & 0xFFFFFFFF)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
         e1 = self._engine(self.nn, G, self.n_sim, self.seed)
         e1.set_roots(grids, ones, game_ids=ids)
         e1.set_sides(side1)

@@ -206,3 +206,15 @@ def test_search_begin_and_end_come_in_pairs():
             eng.pair_with(eng)
     finally:
         eng.close()
+
+
+def test_randomised_arenas_equal_oracle():
+    """tools/fuzz_arena.py: 80 random arenas (game, board size, opponent kind, rounds, start player, simulations, tie mode, overlapped
+    or serial searches, seeds up to 10^6 -- a seed above 42 949 used to overflow the uint32 game ids on the host) against the oracle's
+    arena: every move, the winners and the stats dict"""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_arena
+    assert fuzz_arena.run(80, seed=31, verbose=False) == []

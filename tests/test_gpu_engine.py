@@ -280,3 +280,15 @@ def test_searches_are_replayed_as_hip_graphs():
     os.remove(out)
     for k in ("state", "z", "meta", "visits", "pi"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_randomised_configurations_equal_oracle():
+    """tools/fuzz_engine.py: 150 random configurations -- game, board size (Othello 4 / 6 / 8, Connect4 4x4 .. 8x8, TicTacToe), slot and
+    game counts (slot refill, slot counts that do not fill a wavefront), simulations, Dirichlet alpha / epsilon, temperature schedule
+    (incl. fractional temperatures), tie and noise modes, network-less rollout mode, seed: every sample array bit-equal to the oracle"""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_engine
+    assert fuzz_engine.run(150, seed=2024, verbose=False) == []
