@@ -449,3 +449,15 @@ def test_timers_on_the_device():
     assert nt.timeit(n_batches=3) > 0
     t_hip = nt.timeit_hip(n_batches=60, n_samples=512)
     assert 0 < t_hip < 5e-3
+
+
+def test_randomised_augmentation_equals_host_mirror():
+    """tools/fuzz_augment.py: 120 random sample sets (Othello 6 / 8, Connect4 5x5 .. 8x8, TicTacToe; 0 .. 400 samples; move indices on
+    both sides of the move_idx >= 2 rule) -- the device twins equal the host mirror of the reference's augmentation in order, state,
+    policy, outcome and transformation tag"""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_augment
+    assert fuzz_augment.run(120, seed=9, verbose=False) == []
