@@ -199,3 +199,15 @@ def test_four_waves_per_board_trunk_equals_one_wave_per_board(tag):
     op, ov = onet.forward(canon[:64].cpu().numpy())
     p, v = hnet.forward(canon[:64].contiguous())
     assert np.array_equal(p.cpu().numpy(), op) and np.array_equal(v.cpu().numpy(), ov)
+
+
+def test_randomised_batch_sizes_across_the_kernel_variants():
+    """tools/fuzz_net.py: 200 random launches per run -- batch sizes at and around every row count where the dispatch switches kernels
+    (128 ... 32768, +-1), random board order, plain and device-counted launches -- must reproduce the bits a board gets in a small
+    batch, which are the oracle's"""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_net
+    assert fuzz_net.run(200, seed=12, verbose=False) == []
