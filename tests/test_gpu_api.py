@@ -461,3 +461,16 @@ def test_randomised_augmentation_equals_host_mirror():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_augment
     assert fuzz_augment.run(120, seed=9, verbose=False) == []
+
+
+def test_randomised_single_game_searches_equal_oracle():
+    """tools/fuzz_mct.py: the single-game plugin surface (MCT.search / get_action_probs / get_prior_probs / change_root, tree on the
+    GPU) driven through whole games -- random game and network (or rollout mode), Dirichlet noise on / off, a random number of
+    simulations per ply, random legal moves incl. moves the tree does not hold (fresh root) -- visit counts and priors of every root
+    equal the oracle's"""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_mct
+    assert fuzz_mct.run(25, seed=5, verbose=False) == []

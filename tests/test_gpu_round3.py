@@ -182,3 +182,12 @@ def test_searches_accumulate_on_one_root():
     # a wall-time bounded search on the same tree keeps working too
     mct.search(b, compute_time=0.05)
     assert mct._engine.root_children(0)[4] > root_n
+
+
+def test_randomised_trainer_loops_equal_oracle():
+    """tools/fuzz_trainer.py: random small trainer loops (game, board size, simulations, episodes, batch size, temperature schedule,
+    engine slot count, augmentation on / off, evaluation opponent random / greedy / mcts / previous, seed), two iterations each: the
+    samples of both iterations equal the oracle's self-play with that iteration's weights, every evaluation the oracle's arena"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_trainer
+    assert fuzz_trainer.run(8, seed=77, verbose=False) == []
