@@ -238,3 +238,25 @@ def test_bench_launcher_stops_its_ranks_when_it_is_terminated():
     assert p.returncode == 130
     time.sleep(0.5)
     assert not any(os.path.exists(f"/proc/{k}") and "bench.py" in open(f"/proc/{k}/cmdline").read() for k in kids)
+
+
+def test_bench_under_torch_distributed_run():
+    """the driver's way of starting N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- bench.py is then ONE rank (WORLD_SIZE is set: no self-launch); dry run over gloo"""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, AZ_BENCH_DRYRUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["sum_of_ranks_plus_one"] == 6.0

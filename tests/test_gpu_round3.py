@@ -76,13 +76,21 @@ def test_config5_train_loop_on_othello8_equals_oracle(tmp_path):
     assert set(loss) == {"0", "1"} and len(loss["1"]["0"]["pi"]) == tr.device_memory["z"].shape[0] // 64 and len(loss["0"]["0"]["pi"]) > 0
 
 
-def _rehearse(n, *extra, timeout=1500):
-    """`python bench.py --gpus n` started plainly (no torch.distributed.run) in rehearsal mode: gloo instead of RCCL, every rank on
-    this box's one GPU, tiny sizes -> the parsed JSON line"""
+def _rehearse(n, *extra, timeout=1500, torchrun=False):
+    """`python bench.py --gpus n` started plainly (it launches its own ranks) or, torchrun=True, the way the driver starts it (`python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P bench.py --gpus n ...`), in rehearsal
+    mode: gloo instead of RCCL, every rank on this box's one GPU, tiny sizes -> the parsed JSON line"""
     env = dict(os.environ, AZ_BENCH_BACKEND="gloo", AZ_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--sims", "8", *extra]
+    launcher = [sys.executable]
+    if torchrun:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        launcher += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--sims", "8", *extra]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -113,6 +121,17 @@ def test_bench_launches_its_own_ranks(tmp_path):
     for d in (out["config"], out["roofline"]):
         kinds = [isinstance(x, (dict, list)) for x in d.values()]
         assert kinds == sorted(kinds)
+
+
+def test_bench_as_one_rank_under_torch_distributed_run():
+    """the driver's launch line for N > 1, two ranks in rehearsal mode: headline + saturated + config5 (one variant) come out as under
+    the self-launch"""
+    out = _rehearse(2, "--games", "32", "--saturated-games", "48", "--config3-total", "64", "--config5-episodes", "64",
+                    "--config5-variants", "reference_batch_64", "--config5-eval-episodes", "4", torchrun=True)
+    assert out["n_gpus"] == 2 and len(out["per_rank_ms_per_step"]) == 2 and out["value"] > 0
+    assert out["config"]["concurrent_games_per_gpu"] == 32 and out["saturated"]["concurrent_games"] == 48
+    assert "config3" not in out  # 64 / 2 = the headline's 32 per GPU: config 3 IS the headline
+    assert len(out["config5"]["variants"]["reference_batch_64"]["iterations"]) == 2
 
 
 def test_bench_rehearsal_with_five_ranks_and_an_idle_rank():

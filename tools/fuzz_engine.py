@@ -15,9 +15,10 @@ from oracle import oracle as O  # noqa: E402
 
 
 def sort_samples(d):
-    meta = d["meta"].cpu().numpy()
-    order = np.lexsort((meta[:, 1], meta[:, 0]))
-    return {k: v.cpu().numpy()[order] for k, v in d.items()}
+    """by (game id as uint32, ply): the engine emits samples in lock-step order"""
+    d = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in d.items() if k != "n_evals"}
+    order = np.lexsort((d["meta"][:, 1], d["meta"][:, 0].astype(np.int64) & 0xFFFFFFFF))
+    return {k: v[order] for k, v in d.items()}
 
 
 def run(trials, seed, verbose=True):
@@ -44,7 +45,11 @@ def run(trials, seed, verbose=True):
         tmin = tmax + int(rng.choice([0, 1, 2, 3, 5, 9]))
         tie = int(rng.choice([O.TIE_LOWEST, O.TIE_RANDOM]))
         noise = (int(rng.choice([O.NOISE_PHILOX, O.NOISE_HASH])) if noisy else O.NOISE_OFF)
-        seed, first = int(rng.integers(0, 2**31 - 1)), int(rng.integers(0, 10**6))
+        seed, first = int(rng.integers(0, 2**32)), int(rng.integers(0, 10**6))
+        if rng.random() < 0.06:
+            first = 2**32 - int(rng.integers(1, 6))  # the game ids of the trial wrap around 2^32
+        elif rng.random() < 0.06:
+            first = 2**31 - int(rng.integers(1, 6))  # ... or cross the sign bit of the int32 meta column
         cfg = dict(game=game, H=H, W=W, slots=slots, n_games=n_games, n_sim=n_sim, alpha=alpha, eps=eps, tmax=tmax, tmin=tmin, tie=tie, noise=noise,
                    rollout=rollout, seed=seed, first=first)
         try:
@@ -57,8 +62,10 @@ def run(trials, seed, verbose=True):
             eng.close()
             ref = O.selfplay(game, H, W, n_games, n_sim, ("fake", None), alpha=alpha, eps=eps, temp_max_step=tmax, temp_min_step=tmin, tie_mode=tie,
                              noise_mode=noise, seed=seed, first_game_id=first, eval_method=O.EVAL_ROLLOUT if rollout else O.EVAL_NEURAL)
+            n_evals = ref["n_evals"]
+            ref = sort_samples(ref)
             ok = len(got["z"]) == len(ref["z"]) and all(np.array_equal(got[k], ref[k]) for k in ("state", "z", "meta", "visits", "pi"))
-            ok = ok and st["games_done"] == n_games and (rollout or st["net_evals"] == ref["n_evals"])
+            ok = ok and st["games_done"] == n_games and (rollout or st["net_evals"] == n_evals)
         except Exception as e:  # noqa: BLE001
             ok = False
             cfg["exception"] = repr(e)[:200]
