@@ -727,7 +727,15 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus))  # before torch is imported: the parent never touches HIP
 
+    t_start = time.perf_counter()
+    phases = {}  # wall seconds of this rank per part of the run (rank 0's go into the line as `bench_seconds`)
+
+    def lap(name, since):
+        phases[name] = round(time.perf_counter() - since, 2)
+        return time.perf_counter()
+
     _imports()
+    t_lap = lap("imports", t_start)
     job = Job()
     if job.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={job.world}")
@@ -758,6 +766,7 @@ def main():
         from alphazero_amd.games.othello import OthelloNet
         torch.manual_seed(0)
         cpu = cpu_baseline(OthelloNet(n=8).eval().state_dict())
+        t_lap = lap("cpu_baseline", t_lap)
 
     job.init()
     rank, world = job.rank, job.world
@@ -767,6 +776,7 @@ def main():
     r = timed_waves(job, w, args.steps, args.warmup)
     dt, samples = r["dt"], r["samples"]
     st = w.eng.stats()
+    t_lap = lap("headline_build_warmup_timed", t_lap)
 
     if rank == 0:
         games = args.steps * G * world
@@ -794,21 +804,28 @@ def main():
     w.close()
     if world > 1:
         dist.barrier()
+    t_lap = lap("headline_profiled_step", t_lap)
     saturated = config1 = config3 = config4 = config5 = latency = None
     if not args.no_literal_configs:
         if args.saturated_games and args.saturated_games != args.games:
             saturated = run_saturated(job, args.saturated_games, args.sims, steps=2, warmup=1, first_wave=1000)
+            t_lap = lap("saturated", t_lap)
         if world > 1 and args.config3_total // world != args.games:
             config3 = run_config3(job, args.config3_total, args.sims, steps=2, warmup=1)
+            t_lap = lap("config3", t_lap)
         if world == 1:
             # Othello games all last 60-65 plies: one synchronised wave per step keeps 92 % of the leaf rows filled (the rest are
             # terminal leaves, which need no evaluation).  Connect4 games last 18-42 plies: finished slots are refilled and a
             # step plays 8 x 8192 games, so that the drain at the end of a step (its length is one game) is amortised
             config4 = run_single("config4", "connect4", args.config4_games, 200, steps=2, warmup=1, waves=8)
+            t_lap = lap("config4", t_lap)
             config1 = run_config1()
+            t_lap = lap("config1", t_lap)
         config5 = run_config5(job, args.config5_episodes, args.sims, eval_episodes=args.config5_eval_episodes, only=[v for v in args.config5_variants.split(",") if v] or None)
+        t_lap = lap("config5", t_lap)
         if world == 1:
             latency = run_latency(args.sims)
+            t_lap = lap("latency", t_lap)
     if rank == 0:
         cfg = out["config"]
         cfg["end_to_end_frac"] = roof.get("end_to_end_frac")
@@ -852,6 +869,8 @@ def main():
                           ("latency", latency), ("cpu_baseline", cpu)):
             if obj is not None:
                 out[name] = obj
+        phases["total"] = round(time.perf_counter() - t_start, 2)
+        out["bench_seconds"] = phases  # where the run's wall time went (the timed region is `ms_per_step` x `steps` of "headline_build_warmup_timed")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
