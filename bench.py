@@ -796,6 +796,17 @@ def main():
             # diagnosis of a scaling run: every rank's own step time (before waiting for the others) and its share spent in the RCCL gather
             "per_rank_ms_per_step": r["per_rank_ms_per_step"], "per_rank_gather_ms_per_step": r["per_rank_gather_ms_per_step"],
         }
+        # the boundary hands over DEVICE buffers (az_engine_samples; the trainer's memory stays in HBM).  What a caller who wants the
+        # samples of a step in host memory would pay on top, measured outside the timed region on the last step's samples:
+        smp = w.eng.samples(copy=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        host = [smp[k].cpu() for k in ("state", "pi", "z")]
+        t_host = time.perf_counter() - t0
+        out["config"]["samples_to_host_ms_per_step"] = 1e3 * t_host
+        out["config"]["samples_to_host_mbytes_per_step"] = sum(t.numel() * t.element_size() for t in host) / 1e6
+        out["config"]["games_per_sec_incl_host_copy"] = games / (dt + args.steps * t_host * world)  # every rank would copy the gathered set
+        del host, smp
     if world > 1:
         dist.barrier()
     # the roofline's per-kernel times: one extra step, profiled, outside the timed region (rank 0; the others idle at the barrier)
