@@ -257,6 +257,12 @@ class AlphaZeroTrainer:
                 and torch.device(self.config.device).type == "cuda" and train_step.supports(self.nn_twin, self.config.batch_size)):
             self.sgd_backend_used = "hip"
             return self._optimize_hip(iter_idx)
+        if self.sgd_backend == "hip" and self.device_memory is not None and torch.device(self.config.device).type == "cuda":
+            # never silent: the hand-written step was asked for and does not cover this network / batch size
+            import warnings
+            warnings.warn(f"sgd_backend 'hip' does not cover {type(self.nn_twin).__name__} at batch size {self.config.batch_size} "
+                          f"(csrc/az_train.hip: OthelloNet / Connect4Net at multiples of 16 up to 512, TicTacToeNet at 2..256): "
+                          f"this optimize_network runs the stock PyTorch step", RuntimeWarning, stacklevel=2)
         self.sgd_backend_used = "torch"
         opt = torch.optim.SGD(self.nn_twin.parameters(), lr=self.config.learning_rate, momentum=0.9, weight_decay=0.0001)
         sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)

@@ -162,8 +162,9 @@ def test_backends_are_selectable_and_unsupported_shapes_use_the_stock_step():
     tr.optimize_network(0)
     assert tr.sgd_backend_used == "torch"
     tr2, _ = _fixture_trainer("connect4", "hip")
-    tr2.config.batch_size = 24  # not a multiple of 16: outside the hand-written step's range
-    tr2.optimize_network(0)
+    tr2.config.batch_size = 24  # not a multiple of 16: outside the hand-written step's range -> the stock step, and never silently
+    with pytest.warns(RuntimeWarning, match="stock PyTorch step"):
+        tr2.optimize_network(0)
     assert tr2.sgd_backend_used == "torch"
     from alphazero_amd import train_step
     from alphazero_amd.games.tictactoe import TicTacToeNet
