@@ -2383,10 +2383,210 @@ __global__ void k_mlp(const float *__restrict__ in, int B, const int *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Exact block-fixed-point dense layers on the int8 matrix pipe (AZ_DENSE_I8=1; OthelloNet's fc1 / fc2; the CPU oracle restates the same
+// arithmetic under the same switch, function dense_layer_q).  v_mfma_i32_32x32x32_i8 runs at 32x the rate of the f32-input MFMA
+// and its integer sums are exact, so a float32 layer can be had from it without giving up bit equality:
+//   * a vector of K floats (a row of activations; the K weights of one output column) shares ONE exponent E = the biased f32 exponent of
+//     its largest magnitude (clamped to [1, 254]); q[k] = rint(x[k] * 2^(148 - E)), |q| <= 2^22, is held as three balanced base-256
+//     digits d0 + 256 d1 + 65536 d2 (each in [-128, 127]; non-finite elements quantise to 0);
+//   * the nine digit-plane products of a (row, column) pair are int8 MFMAs accumulated exactly in int32, products of equal weight
+//     256^(i + j) in one accumulator (five per output; |sum| < 2^26 at K = 1024);
+//   * X = sum_s acc_s 256^s is the exact integer dot product of the two quantised vectors -- whatever the tile shape, the K order or the
+//     kernel variant -- and the output is relu((float)ldexp((double)X, E_row + E_col - 296) + bias): X -> double and double -> float
+//     rounded to nearest even once each.
+// Against float64 the form is as close as the float32 fma chain it replaces (OthelloNet 8x8: pi 9e-9, v 1.4e-7; chain: 1.0e-8, 2.0e-7).
+// ---------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+AZ_D int q_value_dev(float x, int E) {
+    const unsigned b = __float_as_uint(x);
+    if ((b & 0x7f800000u) == 0x7f800000u) return 0;
+    return (int)rintf(ldexpf(x, 148 - E));
+}
+AZ_D void q_digits(int q, int &d0, int &d1, int &d2) {
+    d0 = ((q + 128) & 255) - 128;
+    const int q1 = (q - d0) >> 8;
+    d1 = ((q1 + 128) & 255) - 128;
+    d2 = (q1 - d1) >> 8;
+}
+
+// rows of X [M][K] (float32) -> digit planes D[p][row][K] (int8, p = 0: least significant) + the row exponents.  One wave per row.
+__global__ __launch_bounds__(256) void k_q_rows(const float *__restrict__ X, int M, int K, const int *__restrict__ dyn, int8_t *__restrict__ D,
+                                                size_t plane, int *__restrict__ E) {
+    if (dyn) { int c = *dyn; M = c < M ? c : M; }
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;  // wave-uniform
+    const float4 *xr = reinterpret_cast<const float4 *>(X + (size_t)row * K);
+    float4 v[4];
+    unsigned mx = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = c * 64 + lane;
+        v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * i < K) v[c] = xr[i];
+        mx = max(mx, max(max(__float_as_uint(v[c].x) & 0x7fffffffu, __float_as_uint(v[c].y) & 0x7fffffffu),
+                         max(__float_as_uint(v[c].z) & 0x7fffffffu, __float_as_uint(v[c].w) & 0x7fffffffu)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    int Ex = (int)(mx >> 23);
+    Ex = Ex < 1 ? 1 : (Ex > 254 ? 254 : Ex);
+    if (lane == 0) E[row] = Ex;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = c * 64 + lane;
+        if (4 * i >= K) continue;
+        int d[4][3];
+        q_digits(q_value_dev(v[c].x, Ex), d[0][0], d[0][1], d[0][2]);
+        q_digits(q_value_dev(v[c].y, Ex), d[1][0], d[1][1], d[1][2]);
+        q_digits(q_value_dev(v[c].z, Ex), d[2][0], d[2][1], d[2][2]);
+        q_digits(q_value_dev(v[c].w, Ex), d[3][0], d[3][1], d[3][2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned w = (unsigned)(d[0][p] & 255) | ((unsigned)(d[1][p] & 255) << 8) | ((unsigned)(d[2][p] & 255) << 16) | ((unsigned)(d[3][p] & 255) << 24);
+            *reinterpret_cast<unsigned *>(D + p * plane + (size_t)row * K + 4 * i) = w;
+        }
+    }
+}
+
+// the folded weights W [K][N] (float32) -> digit planes D[p][n][K] + the column exponents: one wave per output column (commit time)
+__global__ __launch_bounds__(256) void k_q_cols(const float *__restrict__ W, int K, int N, int8_t *__restrict__ D, int *__restrict__ E) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    unsigned mx = 0;
+    for (int k = lane; k < K; k += 64) mx = max(mx, __float_as_uint(W[(size_t)k * N + n]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    int Ex = (int)(mx >> 23);
+    Ex = Ex < 1 ? 1 : (Ex > 254 ? 254 : Ex);
+    if (lane == 0) E[n] = Ex;
+    const size_t plane = (size_t)N * K;
+    for (int k = lane; k < K; k += 64) {
+        int d0, d1, d2;
+        q_digits(q_value_dev(W[(size_t)k * N + n], Ex), d0, d1, d2);
+        D[(size_t)n * K + k] = (int8_t)d0; D[plane + (size_t)n * K + k] = (int8_t)d1; D[2 * plane + (size_t)n * K + k] = (int8_t)d2;
+    }
+}
+
+// C[M][N] = relu(dequant(A digits x B digits) + bias).  Workgroup = NWM x NWN waves (eight: two per SIMD), wave tile = WM x WN MFMA tiles
+// of 32 x 32, five int32 accumulators per tile (digit products of equal weight).  K is walked in chunks of 32 (one MFMA step).  A chunk
+// of an operand is a set of 1 KB blocks, one per (32 rows, digit plane), laid out [k half h][row r][16 bytes] -- exactly the order in
+// which the 64 lanes of the MFMA fragment read it (lane = 32 h + r: one linear, conflict-free ds_read_b128 per fragment) and exactly what
+// ONE global_load_lds_dwordx4 writes (LDS destination = wave-uniform base + 16 lane; the per-lane SOURCE address picks row r, k half h).
+// The chunks go global -> LDS without touching a register, four stages deep: the loads of chunk kc + 3 are issued while chunk kc is
+// multiplied, each wave waits for ITS loads of chunk kc with a counted s_waitcnt vmcnt, the barrier behind it makes everybody's visible,
+// and the stage being refilled was last read before that barrier.  The int8 A / B fragments pair byte j of lane half h in both
+// operands, so whatever order the instruction walks its 32 k in, every k meets its partner.
+template <int NWM, int NWN, int WM, int WN>
+constexpr int qgemm_lds_bytes() { return 4 * 3 * (NWM * WM + NWN * WN) * 1024; }
+
+template <int NWM, int NWN, int WM, int WN, bool RELU>
+__global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 ? 2 : 1)) void k_qgemm(const int8_t *__restrict__ Ad, size_t planeA, const int *__restrict__ Ea, const int8_t *__restrict__ Bd,
+                                                          size_t planeB, const int *__restrict__ Eb, const float *__restrict__ bias, float *__restrict__ C, int M,
+                                                          int N, int K, const int *__restrict__ dyn) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (the LDS-DMA builtin and the counted waits exist on the device side only)
+    if (dyn) { int c = *dyn; M = c < M ? c : M; }
+    constexpr int NW = NWM * NWN, GA = NWM * WM, GB = NWN * WN, BM = GA * 32, BN = GB * 32, NBLK = 3 * (GA + GB), PER = (NBLK + NW - 1) / NW, STAGE = NBLK * 1024;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= M) return;  // uniform
+    extern __shared__ __attribute__((aligned(16))) int8_t qlds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave / NWN, wn = wave % NWN, r = lane & 31, h = lane >> 5;
+    v16i acc[WM][WN][5];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int s5 = 0; s5 < 5; ++s5)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc[i][j][s5][t] = 0;
+    // this wave's blocks of a chunk (a wave with one block fewer than the others loads the chunk's first blocks once more: every wave
+    // then has PER loads per chunk in flight, which is what the counted waits assume)
+    const int8_t *src[PER];
+    int dst[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        int b = wave + NW * e;
+        if (b >= NBLK) b -= NBLK;
+        const bool isA = b < 3 * GA;
+        const int g = (isA ? b : b - 3 * GA) / 3, p = (isA ? b : b - 3 * GA) % 3;
+        src[e] = isA ? Ad + p * planeA + (size_t)(m0 + 32 * g + r) * K + 16 * h : Bd + p * planeB + (size_t)(n0 + 32 * g + r) * K + 16 * h;
+        dst[e] = b * 1024;
+    }
+    const int NKC = K / 32;
+#define QG_ISSUE(kc_)                                                                                                                           \
+    _Pragma("unroll") for (int e = 0; e < PER; ++e)                                                                                             \
+        __builtin_amdgcn_global_load_lds(src[e] + (kc_) * 32, (__attribute__((address_space(3))) void *)(qlds + ((kc_) & 3) * STAGE + dst[e]), 16, 0, 0);
+    QG_ISSUE(0)
+    if (NKC > 1) QG_ISSUE(1)
+    if (NKC > 2) QG_ISSUE(2)
+    for (int kc = 0; kc < NKC; ++kc) {
+        // my loads of chunk kc have landed when at most the later chunks' (two, one or none) are still in flight
+        if (kc + 2 < NKC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+        else if (kc + 1 < NKC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kc + 3 < NKC) QG_ISSUE(kc + 3)  // into the stage chunk kc - 1 was read from: everybody is past that
+        const int8_t *St = qlds + (kc & 3) * STAGE + 16 * lane;
+        v4i a[WM][3], b[WN][3];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const v4i *>(St + ((wm * WM + i) * 3 + p) * 1024);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const v4i *>(St + (3 * GA + (wn * WN + j) * 3 + p) * 1024);
+        // the nine digit pairs in an order that keeps two MFMAs on one accumulator apart
+#define QG_PAIR(PA_, PB_)                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                                \
+        acc[i][j][PA_ + PB_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i][PA_], b[j][PB_], acc[i][j][PA_ + PB_], 0, 0, 0);
+        QG_PAIR(0, 0) QG_PAIR(0, 1) QG_PAIR(0, 2) QG_PAIR(1, 2) QG_PAIR(2, 2) QG_PAIR(1, 0) QG_PAIR(1, 1) QG_PAIR(2, 1) QG_PAIR(2, 0)
+#undef QG_PAIR
+    }
+#undef QG_ISSUE
+    // C layout of 32x32: column lane & 31, row (t & 3) + 8 (t >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        int ea[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int row = m0 + (wm * WM + i) * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+            ea[t] = Ea[row] - 296;  // rows past M lie inside the buffer (a whole tile of rows is allocated)
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + (wn * WN + j) * 32 + r;
+            const int eb = Eb[col];
+            const float bv = bias[col];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int row = m0 + (wm * WM + i) * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+                const double hi = fma((double)acc[i][j][4][t], 65536.0, fma((double)acc[i][j][3][t], 256.0, (double)acc[i][j][2][t]));
+                const double lo = fma((double)acc[i][j][1][t], 256.0, (double)acc[i][j][0][t]);
+                const double x = fma(hi, 65536.0, lo);  // = (double)X, one rounding
+                float v = (float)ldexp(x, ea[t] + eb) + bv;
+                if (RELU) v = v > 0.0f ? v : 0.0f;
+                if (row < M) C[(size_t)row * N + col] = v;
+            }
+        }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 // layers k_dense_frag can run: K in whole 128-k groups of fragments (PF = 8 loads of 16 k), the 16 rows of K + 4 floats within the LDS
 static bool frag_shape(int N, int K) { return N % 64 == 0 && K % 128 == 0 && K <= 2048; }
+
+// AZ_DENSE_I8=1: OthelloNet's fc1 / fc2 in the exact block-fixed-point form (k_q_rows + k_qgemm); the CPU oracle reads the same variable
+static bool use_qdense(int game) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("AZ_DENSE_I8"); v = (e && atoi(e) == 1) ? 1 : 0; }
+    return v == 1 && game == AZ_OTHELLO;
+}
 
 struct az_net {
     int game, H, W, CH, CW, A, F1, F2, FIN, NH, max_batch;
@@ -2398,6 +2598,12 @@ struct az_net {
     float *hwq = nullptr;  // head matrix in 16x16x4 B-fragment order [F2/16][NH/16][64 lanes][4] (k_heads2)
     float *fc1wq = nullptr, *fc2wq = nullptr;  // fc1 / fc2 in the same fragment order (k_dense_frag); null where the shapes do not tile
     float *feat, *h1, *h2;
+    // exact block-fixed-point dense layers (AZ_DENSE_I8=1, OthelloNet): digit planes + exponents of the two weight matrices and of the
+    // activation rows (one buffer, used by fc1 and then by fc2)
+    bool qd_on = false;
+    int8_t *qd_w1 = nullptr, *qd_w2 = nullptr, *qd_a = nullptr;
+    int *qd_e1 = nullptr, *qd_e2 = nullptr, *qd_ea = nullptr;
+    size_t qd_rows = 0;  // rows of a digit plane of qd_a (max_batch rounded up to a whole tile)
     MlpParams mlp;           // host staging of the TicTacToe MLP
     MlpParams *mlp_dev = nullptr;  // what k_mlp reads
     bool committed;
@@ -2458,6 +2664,18 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
         if (frag_shape(n->F1, n->FIN)) { NA(n->fc1wq, (size_t)n->FIN * n->F1) }
         if (frag_shape(n->F2, n->F1)) { NA(n->fc2wq, (size_t)n->F1 * n->F2) }
         NA(n->feat, (size_t)max_batch * n->FIN) NA(n->h1, (size_t)max_batch * n->F1) NA(n->h2, (size_t)max_batch * n->F2)
+        n->qd_on = use_qdense(game) && n->FIN % 64 == 0 && n->F1 % 128 == 0 && n->F2 % 128 == 0 && n->F1 <= 1024 && n->FIN <= 1024;
+        if (n->qd_on) {
+            n->qd_rows = ((size_t)max_batch + 127) / 128 * 128;
+            const size_t kmax = (size_t)(n->FIN > n->F1 ? n->FIN : n->F1);
+            NA(p, (3 * (size_t)n->F1 * n->FIN + 3) / 4) n->qd_w1 = reinterpret_cast<int8_t *>(p);
+            NA(p, (3 * (size_t)n->F2 * n->F1 + 3) / 4) n->qd_w2 = reinterpret_cast<int8_t *>(p);
+            NA(p, (3 * n->qd_rows * kmax + 3) / 4) n->qd_a = reinterpret_cast<int8_t *>(p);
+            NA(p, n->F1) n->qd_e1 = reinterpret_cast<int *>(p);
+            NA(p, n->F2) n->qd_e2 = reinterpret_cast<int *>(p);
+            NA(p, n->qd_rows) n->qd_ea = reinterpret_cast<int *>(p);
+            if (rc == AZ_OK && hipMemset(n->qd_a, 0, 3 * n->qd_rows * kmax) != hipSuccess) rc = AZ_EHIP;  // rows past the batch are read by the last tile, never stored
+        }
 #undef NA
         if (rc != AZ_OK) { az_net_destroy(n); return rc; }
     } else {
@@ -2530,6 +2748,16 @@ static int upload(float *dst, const std::vector<float> &src, hipStream_t st) {
 static int retile_q(const float *w, float *dst, int K, int N, hipStream_t st) {
     if (!dst) return AZ_OK;
     hipLaunchKernelGGL(k_retile_q, dim3((unsigned)(((size_t)K * N + 255) / 256)), dim3(256), 0, st, w, dst, K, N);
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+// the digit planes of a folded dense matrix (AZ_DENSE_I8)
+static int quant_w(az_net *n, int layer, hipStream_t st) {
+    if (!n->qd_on) return AZ_OK;
+    const int K = layer == 1 ? n->FIN : n->F1, N = layer == 1 ? n->F1 : n->F2;
+    hipLaunchKernelGGL(k_q_cols, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, layer == 1 ? n->fc1w : n->fc2w, K, N, layer == 1 ? n->qd_w1 : n->qd_w2,
+                       layer == 1 ? n->qd_e1 : n->qd_e2);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
@@ -2659,6 +2887,7 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
         }
         AZ_TRY(upload(n->fc1w, fw, st)); AZ_TRY(upload(n->fc1b, fb, st));
         AZ_TRY(retile_q(n->fc1w, n->fc1wq, n->FIN, n->F1, st));
+        AZ_TRY(quant_w(n, 1, st));
     }
     {
         AZ_TRY(bn_scale(n, "fc_bn2", n->F2, s, mean, beta));
@@ -2670,6 +2899,7 @@ extern "C" int az_net_commit(az_net *n, void *stream) {
         }
         AZ_TRY(upload(n->fc2w, fw, st)); AZ_TRY(upload(n->fc2b, fb, st));
         AZ_TRY(retile_q(n->fc2w, n->fc2wq, n->F1, n->F2, st));
+        AZ_TRY(quant_w(n, 2, st));
     }
     {
         const std::vector<float> *pw, *pb, *vw, *vb;
@@ -2862,9 +3092,11 @@ extern "C" int az_net_commit_device(az_net *n, void *stream) {
     AZ_TRY(fold_launch(n, FOLD_DENSE_T, n->fc1w, n->FIN * n->F1, "fc1.weight", (size_t)n->F1 * n->FIN, "", 0, "fc_bn1", n->F1, n->FIN, n->F1, 0, st));
     AZ_TRY(fold_launch(n, FOLD_BIAS, n->fc1b, n->F1, "", 0, "fc1.bias", n->F1, "fc_bn1", n->F1, 0, 0, 0, st));
     AZ_TRY(retile_q(n->fc1w, n->fc1wq, n->FIN, n->F1, st));
+        AZ_TRY(quant_w(n, 1, st));
     AZ_TRY(fold_launch(n, FOLD_DENSE_T, n->fc2w, n->F1 * n->F2, "fc2.weight", (size_t)n->F2 * n->F1, "", 0, "fc_bn2", n->F2, n->F1, n->F2, 0, st));
     AZ_TRY(fold_launch(n, FOLD_BIAS, n->fc2b, n->F2, "", 0, "fc2.bias", n->F2, "fc_bn2", n->F2, 0, 0, 0, st));
     AZ_TRY(retile_q(n->fc2w, n->fc2wq, n->F1, n->F2, st));
+        AZ_TRY(quant_w(n, 2, st));
     AZ_TRY(fold_launch(n, FOLD_HEADS_W, n->hw, n->F2 * n->NH, "fc_probs.weight", (size_t)n->A * n->F2, "fc_value.weight", n->F2, "", 0, n->F2, n->NH, n->A, st));
     AZ_TRY(fold_launch(n, FOLD_HEADS_B, n->hb, n->NH, "fc_probs.bias", n->A, "fc_value.bias", 1, "", 0, 0, n->NH, n->A, st));
     if (n->F2 % 16 == 0)
@@ -3104,6 +3336,38 @@ static int launch_gemm(const float *A, const float *Bw, const float *Bq, const f
     return AZ_EINVAL;
 }
 
+template <int NWM, int NWN, int WM, int WN>
+static int qgemm_go(az_net *n, int layer, int B, const int *dyn, hipStream_t st) {
+    constexpr int lds = qgemm_lds_bytes<NWM, NWN, WM, WN>(), BM = NWM * WM * 32, BN = NWN * WN * 32;
+    static_assert(lds <= 160 * 1024, "k_qgemm does not fit the CU's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        AZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_qgemm<NWM, NWN, WM, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int K = layer == 1 ? n->FIN : n->F1, N = layer == 1 ? n->F1 : n->F2;
+    AZ_LAUNCH((k_qgemm<NWM, NWN, WM, WN, true>), dim3((unsigned)(N / BN), (unsigned)((B + BM - 1) / BM)), dim3(64 * NWM * NWN), lds, st, n->qd_a,
+              n->qd_rows * (size_t)K, n->qd_ea, layer == 1 ? n->qd_w1 : n->qd_w2, (size_t)N * K, layer == 1 ? n->qd_e1 : n->qd_e2, layer == 1 ? n->fc1b : n->fc2b,
+              layer == 1 ? n->h1 : n->h2, B, N, K, dyn);
+    return AZ_OK;
+}
+
+// fc1 / fc2 in the exact block-fixed-point form: quantise the rows of the layer's input, then the int8 GEMM
+static int launch_qdense(az_net *n, int layer, int B, const int *dyn, hipStream_t st) {
+    const int K = layer == 1 ? n->FIN : n->F1, N = layer == 1 ? n->F1 : n->F2;
+    hipLaunchKernelGGL(k_q_rows, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, layer == 1 ? n->feat : n->h1, B, K, dyn, n->qd_a, n->qd_rows * (size_t)K, n->qd_ea);
+    static int cfg = -1;  // AZ_QG_CFG: tile plan for A/B runs (every plan gives the same bits)
+    if (cfg < 0) { const char *e = getenv("AZ_QG_CFG"); cfg = e ? atoi(e) : 0; }
+    if (cfg == 1) return qgemm_go<2, 2, 1, 2>(n, layer, B, dyn, st);  // 64 x 128, four waves, two workgroups per CU
+    if (cfg == 2) return qgemm_go<2, 2, 1, 1>(n, layer, B, dyn, st);  // 64 x 64, four waves
+    if (cfg == 3) return qgemm_go<4, 2, 1, 1>(n, layer, B, dyn, st);  // 128 x 64, eight waves
+    if (cfg == 4) return qgemm_go<4, 2, 1, 2>(n, layer, B, dyn, st);  // 128 x 128, eight waves
+    if (cfg == 5) return qgemm_go<2, 4, 1, 1>(n, layer, B, dyn, st);  // 64 x 128, eight waves
+    // 128 x 128 tiles from one workgroup per CU up, 64 x 128 below
+    if ((long long)((B + 127) / 128) * (N / 128) >= 256) return qgemm_go<4, 2, 1, 2>(n, layer, B, dyn, st);
+    return qgemm_go<2, 4, 1, 1>(n, layer, B, dyn, st);
+}
+
 template <int NT>
 static int heads_go(az_net *n, int B, float *probs, float *value, const int *dyn, hipStream_t st) {
     constexpr int lds = heads_lds_bytes<NT>();
@@ -3230,8 +3494,8 @@ static int run_stage(az_net *n, int stage, const float *d_input, int B, const in
             if (n->CH == 6 && n->CW == 6) return launch_trunk<6, 6, false>(n, d_input, B, dyn, st);
             if (n->CH == 7 && n->CW == 6) return use_wino(7, 6) ? launch_trunk<7, 6, true>(n, d_input, B, dyn, st) : launch_trunk<7, 6, false>(n, d_input, B, dyn, st);
             return launch_trunk_other(n, d_input, B, dyn, st);
-        case 1: return launch_gemm(n->feat, n->fc1w, n->fc1wq, n->fc1b, n->h1, B, n->F1, n->FIN, true, dyn, st);
-        case 2: return launch_gemm(n->h1, n->fc2w, n->fc2wq, n->fc2b, n->h2, B, n->F2, n->F1, true, dyn, st);
+        case 1: return n->qd_on ? launch_qdense(n, 1, B, dyn, st) : launch_gemm(n->feat, n->fc1w, n->fc1wq, n->fc1b, n->h1, B, n->F1, n->FIN, true, dyn, st);
+        case 2: return n->qd_on ? launch_qdense(n, 2, B, dyn, st) : launch_gemm(n->h1, n->fc2w, n->fc2wq, n->fc2b, n->h2, B, n->F2, n->F1, true, dyn, st);
         default: return launch_heads(n, B, d_probs, d_value, dyn, st);
     }
 }
@@ -3375,6 +3639,7 @@ extern "C" int az_net_stage_kernel(const az_net *n, int stage, int B, char *buf,
         name = (tuned && !trunk_v1() && B >= 4096) ? (use_wino(n->CH, n->CW) ? "k_trunk2<Winograd conv2>" : "k_trunk2") : ((tuned && B <= trunk_q_max()) ? "k_trunk_q" : "k_trunk");
     }
     else if (stage == 3) name = (B <= heads_small_max(n) && n->NH <= 128 && n->F2 % 32 == 0) ? "k_heads_small" : (n->F2 == 512 ? "k_heads2" : "k_heads");
+    else if (n->qd_on) name = "k_qgemm";
     else {
         const int N = stage == 1 ? n->F1 : n->F2, K = stage == 1 ? n->FIN : n->F1;
         switch (gemm_kind(B, N, K, (stage == 1 ? n->fc1wq : n->fc2wq) != nullptr)) {

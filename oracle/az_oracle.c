@@ -405,6 +405,9 @@ struct orc_convnet {
     float *c2u;     /* conv2 for the Winograd F(2x2,3x3) form: U[16 frequencies][32 ic][32 oc] = G g' G^T (float64, rounded once) */
     int wino;       /* conv2 runs in the Winograd form (the product's choice for this plane shape) */
     float *f1w, *f1b, *f2w, *f2b; /* [K][N] transposed for vectorisation over N */
+    int qdense;                   /* fc1 / fc2 in the exact block-fixed-point form (the product's AZ_DENSE_I8 switch) */
+    int32_t *f1q, *f2q;           /* quantised folded weights [N][K] */
+    int *f1e, *f2e;               /* their per-output-column exponents */
     float *hw, *hb;               /* heads: [512][A+1] (last column = value) */
     int folded;
 };
@@ -415,7 +418,10 @@ static float *dupf(const float *d, int64_t n) {
     return p;
 }
 
+static void q_weights(const float *w, int K, int N, int32_t **q, int **e);
 void orc_convnet_set_winograd(orc_convnet *n, int on) { n->wino = on; }
+void orc_convnet_set_qdense(orc_convnet *n, int on) { n->qdense = on && n->game == ORC_OTHELLO; }
+int orc_convnet_qdense(const orc_convnet *n) { return n->qdense; }
 int orc_convnet_winograd(const orc_convnet *n) { return n->wino; }
 
 orc_convnet *orc_convnet_create(int game, int H, int W) {
@@ -429,6 +435,10 @@ orc_convnet *orc_convnet_create(int game, int H, int W) {
         const int mode = e ? atoi(e) : -1;
         n->wino = mode != 0 && ((n->ch == 8 && n->cw == 8) || (n->ch == 7 && n->cw == 6));
     }
+    {   /* the product's policy (use_qdense in az_net.hip): OthelloNet's fc1 / fc2 in the exact block-fixed-point form when AZ_DENSE_I8=1 */
+        const char *e = getenv("AZ_DENSE_I8");
+        n->qdense = game == ORC_OTHELLO && e && atoi(e) == 1;
+    }
     n->FIN = NCH * (n->ch - 4) * (n->cw - 4);
     return n;
 }
@@ -440,6 +450,7 @@ void orc_convnet_destroy(orc_convnet *n) {
         free(n->cw_f[i]); free(n->cb_f[i]);
     }
     for (int i = 0; i < 2; ++i) { free(n->fbn_g[i]); free(n->fbn_b[i]); free(n->fbn_m[i]); free(n->fbn_v[i]); }
+    free(n->f1q); free(n->f2q); free(n->f1e); free(n->f2e);
     free(n->fc1_w); free(n->fc1_b); free(n->fc2_w); free(n->fc2_b); free(n->fp_w); free(n->fp_b); free(n->fv_w); free(n->fv_b);
     free(n->f1w); free(n->f1b); free(n->f2w); free(n->f2b); free(n->hw); free(n->hb); free(n->c2u);
     free(n);
@@ -530,6 +541,10 @@ int orc_convnet_fold(orc_convnet *n) {
         double s = (double)n->fbn_g[1][j] / sqrt((double)n->fbn_v[1][j] + BN_EPS);
         n->f2b[j] = (float)(((double)n->fc2_b[j] - (double)n->fbn_m[1][j]) * s + (double)n->fbn_b[1][j]);
         for (int k = 0; k < n->F1; ++k) n->f2w[(size_t)k * n->F2 + j] = (float)((double)n->fc2_w[(size_t)j * n->F1 + k] * s);
+    }
+    if (n->game == ORC_OTHELLO) {  /* always prepared: orc_convnet_set_qdense may switch the form on after the fold */
+        q_weights(n->f1w, n->FIN, n->F1, &n->f1q, &n->f1e);
+        q_weights(n->f2w, n->F1, n->F2, &n->f2q, &n->f2e);
     }
     int A1 = n->A + 1;
     n->hw = (float *)malloc(sizeof(float) * (size_t)n->F2 * A1); n->hb = (float *)malloc(sizeof(float) * A1);
@@ -629,6 +644,54 @@ static void conv2_winograd(const float *in, int ih, int iw, const float *U, cons
         }
 }
 
+/* ---- exact block-fixed-point dense layers (AZ_DENSE_I8=1; az_net.hip: k_q_rows, k_q_cols, k_qgemm on v_mfma_i32_32x32x32_i8) ----
+ * A vector x[0..K) (a row of activations, or the K weights of one output) shares one exponent: E = biased f32 exponent of max |x|
+ * (clamped to [1, 254]), q[k] = rint(x[k] * 2^(148 - E)), so |q| <= 2^22 (three balanced base-256 digits on the GPU); non-finite
+ * elements quantise to 0.  A dot product is the EXACT integer X = sum q_a q_b (any summation order gives the same X: every kernel
+ * variant and tile shape agrees bit for bit by construction), and the layer's output is
+ *   relu( (float)ldexp((double)X, E_a + E_b - 296) + bias )
+ * with the int64 -> double and the double -> float conversions each rounded to nearest even. */
+static int q_exponent(const float *x, int K, int stride) {
+    uint32_t mx = 0;
+    for (int k = 0; k < K; ++k) {
+        uint32_t b;
+        memcpy(&b, &x[(size_t)k * stride], 4);
+        b &= 0x7fffffffu;
+        if (b > mx) mx = b;
+    }
+    int E = (int)(mx >> 23);
+    return E < 1 ? 1 : (E > 254 ? 254 : E);
+}
+static int32_t q_value(float x, int E) {
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    if ((b & 0x7f800000u) == 0x7f800000u) return 0;
+    return (int32_t)rintf(ldexpf(x, 148 - E));
+}
+/* the folded weights w[K][N] -> q[N][K], e[N] */
+static void q_weights(const float *w, int K, int N, int32_t **q, int **e) {
+    free(*q); free(*e);
+    *q = (int32_t *)malloc(sizeof(int32_t) * (size_t)K * N);
+    *e = (int *)malloc(sizeof(int) * (size_t)N);
+    for (int j = 0; j < N; ++j) {
+        const int E = q_exponent(w + j, K, N);
+        (*e)[j] = E;
+        for (int k = 0; k < K; ++k) (*q)[(size_t)j * K + k] = q_value(w[(size_t)k * N + j], E);
+    }
+}
+static void dense_layer_q(const float *x, int K, const int32_t *wq, const int *we, const float *b, int N, float *out, int relu) {
+    int32_t qa[4096];
+    const int Ea = q_exponent(x, K, 1);
+    for (int k = 0; k < K; ++k) qa[k] = q_value(x[k], Ea);
+    for (int j = 0; j < N; ++j) {
+        const int32_t *qb = wq + (size_t)j * K;
+        int64_t X = 0;
+        for (int k = 0; k < K; ++k) X += (int64_t)qa[k] * (int64_t)qb[k];
+        float v = (float)ldexp((double)X, Ea + we[j] - 296) + b[j];
+        out[j] = (relu && !(v > 0.0f)) ? 0.0f : v;
+    }
+}
+
 /* dense layer: acc[n] = b[n]; for k ascending: acc[n] = fmaf(x[k], W[k][n], acc[n]) */
 static void dense_layer(const float *x, int K, const float *w, const float *b, int N, float *out, int relu) {
     for (int j = 0; j < N; ++j) out[j] = b[j];
@@ -666,8 +729,13 @@ void orc_convnet_forward(const orc_convnet *n, const float *input, int B, float 
         else conv_layer(a1, NCH, ch, cw, 1, n->cw_f[1], n->cb_f[1], a2, ch, cw);      /* :371 */
         conv_layer(a2, NCH, ch, cw, 0, n->cw_f[2], n->cb_f[2], a3, ch - 2, cw - 2);   /* :372 */
         conv_layer(a3, NCH, ch - 2, cw - 2, 0, n->cw_f[3], n->cb_f[3], a4, ch - 4, cw - 4); /* :373 */
+        if (n->qdense) {
+            dense_layer_q(a4, n->FIN, n->f1q, n->f1e, n->f1b, n->F1, h1, 1);            /* :376, exact fixed-point form */
+            dense_layer_q(h1, n->F1, n->f2q, n->f2e, n->f2b, n->F2, h2, 1);             /* :377 */
+        } else {
         dense_layer(a4, n->FIN, n->f1w, n->f1b, n->F1, h1, 1);                          /* :376 (dropout off in eval) */
         dense_layer(h1, n->F1, n->f2w, n->f2b, n->F2, h2, 1);                           /* :377 */
+        }
         dense_layer(h2, n->F2, n->hw, n->hb, n->A + 1, lg, 0);                          /* :379-380 */
         softmax_det(lg, n->A, probs + (size_t)b * n->A);                                /* :382 + base.py:355 */
         v[b] = orc_det_tanhf(lg[n->A]);

@@ -75,6 +75,8 @@ void orc_convnet_destroy(orc_convnet *n);
 /* conv2 in the Winograd F(2x2,3x3) form (what the HIP trunk kernels compute for 8x8 and 7x6 planes) or as a direct conv */
 void orc_convnet_set_winograd(orc_convnet *n, int on);
 int orc_convnet_winograd(const orc_convnet *n);
+void orc_convnet_set_qdense(orc_convnet *n, int on);  /* fc1 / fc2 of OthelloNet in the exact block-fixed-point form (AZ_DENSE_I8) */
+int orc_convnet_qdense(const orc_convnet *n);
 /* name = state_dict key ("conv1.weight", "bn1.running_var", ...); returns 0 ok */
 int orc_convnet_set_tensor(orc_convnet *n, const char *name, const float *data, int64_t numel);
 int orc_convnet_fold(orc_convnet *n); /* fold eval-mode BN into weights; 0 ok */

@@ -90,6 +90,8 @@ def lib():
     L.orc_convnet_folded.restype = C.POINTER(C.c_float)
     L.orc_convnet_set_winograd.argtypes = [C.c_void_p, C.c_int]
     L.orc_convnet_winograd.argtypes = [C.c_void_p]
+    L.orc_convnet_set_qdense.argtypes = [C.c_void_p, C.c_int]
+    L.orc_convnet_qdense.argtypes = [C.c_void_p]
     L.orc_mlpnet_create.restype = C.c_void_p
     L.orc_mlpnet_destroy.argtypes = [C.c_void_p]
     L.orc_mlpnet_set_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
@@ -203,6 +205,13 @@ class ConvNet:
 
     def winograd(self):
         return bool(lib().orc_convnet_winograd(self.h))
+
+    def set_qdense(self, on):
+        """fc1 / fc2 of OthelloNet in the exact block-fixed-point form (the product's AZ_DENSE_I8=1) or as float32 fma chains"""
+        lib().orc_convnet_set_qdense(self.h, 1 if on else 0)
+
+    def qdense(self):
+        return bool(lib().orc_convnet_qdense(self.h))
 
     def folded(self, name):
         n = C.c_int64()

@@ -1,6 +1,7 @@
 """G2: the oracle's network forward (BN folded, fmaf chains in the HIP kernels' accumulation order)
 against the reference's torch forward under closed-form weights.  Tolerance 1e-5 abs."""
 import ast
+import os
 
 import numpy as np
 import pytest
@@ -98,3 +99,38 @@ def test_winograd_form_of_conv2_meets_the_reference_tolerance(tag):
     assert np.abs(p0 - fx["probs"]).max() < 1e-5 and np.abs(v0 - fx["v"]).max() < 1e-5
     assert np.abs(p1 - fx["probs"]).max() < 1e-5 and np.abs(v1 - fx["v"]).max() < 1e-5
     assert np.abs(p1 - p0).max() < 1e-6 and not (np.array_equal(p1, p0) and np.array_equal(v1, v0))
+
+
+def test_fixed_point_dense_form_of_the_oracle():
+    """AZ_DENSE_I8 (oracle/az_oracle.c dense_layer_q): fc1 / fc2 of OthelloNet as exact integer dot products of block-fixed-point operands.
+    Against the float64 forward it must be as close as the float32 fma chain it replaces; the switch is per network and off by default."""
+    import torch
+    from alphazero_amd.games.othello import OthelloNet
+    torch.manual_seed(5)
+    net = OthelloNet(n=8).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    sd = {k: v.numpy() for k, v in net.state_dict().items() if v.dtype == torch.float32}
+    orc = O.ConvNet(O.OTHELLO, 8, 8, sd)
+    assert not orc.qdense() or os.environ.get("AZ_DENSE_I8") == "1"
+    rng = np.random.default_rng(2)
+    x = rng.integers(-1, 2, size=(48, 64)).astype(np.float32)
+    x[5] = 0.0
+    orc.set_qdense(False)
+    p0, v0 = orc.forward(x)
+    orc.set_qdense(True)
+    assert orc.qdense()
+    p1, v1 = orc.forward(x)
+    net64 = OthelloNet(n=8).double().eval()
+    net64.load_state_dict({k: (v.double() if v.dtype == torch.float32 else v) for k, v in net.state_dict().items()})
+    with torch.no_grad():
+        lp, v = net64(torch.tensor(x.reshape(-1, 8, 8), dtype=torch.float64))
+    p, v = lp.exp().numpy(), v.numpy().ravel()
+    assert not np.array_equal(p0, p1)  # a different arithmetic ...
+    assert np.abs(p1 - p).max() < 2e-7 and np.abs(v1 - v).max() < 1e-6  # ... as exact as the chain
+    assert np.abs(p1 - p).max() < 3 * np.abs(p0 - p).max() + 1e-8 and np.abs(v1 - v).max() < 3 * np.abs(v0 - v).max() + 1e-7
+    c4 = O.ConvNet(O.CONNECT4, 6, 7, {k: v.numpy() for k, v in __import__("alphazero_amd.games.connect4", fromlist=["Connect4Net"]).Connect4Net(7, 6).eval().state_dict().items() if v.dtype == torch.float32})
+    c4.set_qdense(True)
+    assert not c4.qdense()  # OthelloNet only
