@@ -862,6 +862,8 @@ def main():
                             "config5_10_epochs_sgd_share": v10["iterations"][1]["sgd_share"],
                             "config5_10_epochs_sgd_ms_per_step": v10["iterations"][1]["sgd_ms_per_step"]})
         cfg["timed_region"] = "engine as shipped: HIP-graph replays, no event recording"
+        cfg["dense_layers"] = ("exact block-fixed-point on the int8 matrix pipe (AZ_DENSE_I8=1: the roofline's f32 MFMA peak does not price fc1 / fc2)"
+                               if os.environ.get("AZ_DENSE_I8") == "1" else "float32 fma chains on the f32-input MFMA")
         if saturated is not None and saturated.get("roofline"):
             roof["saturated_frac"], roof["saturated_end_to_end_frac"] = saturated["roofline"]["frac"], saturated["roofline"].get("end_to_end_frac")
             roof["saturated_kernel"] = saturated["roofline"]["kernel"][:40]
