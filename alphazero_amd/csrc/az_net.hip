@@ -2575,6 +2575,111 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 ? 2 : 1)) void k_qg
 #endif
 }
 
+// The same layer for a handful of rows (the latency regime: one game's search, small waves): 16 rows x 64 columns per workgroup, no
+// separate quantisation launch.  Every thread fetches its share of the 16 rows into registers (one round trip), the rows' largest
+// magnitudes are reduced with shuffles and one exchange through LDS, the digits are formed from the registers and written to LDS as
+// three planes; wave w then owns the 16-column tile w: v_mfma_i32_16x16x64_i8, its weight fragments (16 bytes per lane, digit plane and
+// 64-k step) straight from L2 and requested before anything else.  Five int32 accumulators: the dependent chain is K / 64 steps of two
+// or three MFMAs instead of the K / 4 dependent f32 MFMAs of k_dense_frag.  Same X, same epilogue: the same bits as k_qgemm.
+template <int K, bool RELU>
+__global__ __launch_bounds__(256) void k_qdense_small(const float *__restrict__ X, const int8_t *__restrict__ Bd, size_t planeB, const int *__restrict__ Eb,
+                                                      const float *__restrict__ bias, float *__restrict__ C, int M, int N, const int *__restrict__ dyn) {
+    if (dyn) { int c = *dyn; M = c < M ? c : M; }
+    const int row0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+    if (row0 >= M) return;  // uniform
+    constexpr int N4 = K / 4, IT = 16 * N4 / 256, DS = K + 16, P = N4 >= 64 ? N4 / 64 : 1, W = N4 >= 64 ? 64 : N4, NS = K / 64, HS = NS < 8 ? NS : 8;
+    static_assert(IT * 256 == 16 * N4 && (N4 >= 64 ? N4 % 64 == 0 : 64 % N4 == 0), "whole float4s per thread, whole rows per wave part");
+    __shared__ __attribute__((aligned(16))) int8_t dq[3 * 16 * DS];
+    __shared__ unsigned pm[16][P];
+    __shared__ int es[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ncol = n0 + 16 * wave + (lane & 15), kq = lane >> 4;
+    const int8_t *wb = Bd + (size_t)ncol * K + 16 * kq;
+    v4i bf[HS][3];  // this wave's weight fragments of the first 512 k: they do not depend on the rows
+#pragma unroll
+    for (int st = 0; st < HS; ++st)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[st][p] = *reinterpret_cast<const v4i *>(wb + p * planeB + 64 * st);
+    float4 v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int q = tid + 256 * i, r = q / N4, c = q % N4;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < M) v[i] = reinterpret_cast<const float4 *>(X + (size_t)(row0 + r) * K)[c];
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int q = tid + 256 * i, r = q / N4, c = q % N4;
+        unsigned mx = max(max(__float_as_uint(v[i].x) & 0x7fffffffu, __float_as_uint(v[i].y) & 0x7fffffffu),
+                          max(__float_as_uint(v[i].z) & 0x7fffffffu, __float_as_uint(v[i].w) & 0x7fffffffu));
+#pragma unroll
+        for (int o = W / 2; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        if ((c & (W - 1)) == 0) pm[r][c / W % P] = mx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int q = tid + 256 * i, r = q / N4, c = q % N4;
+        unsigned mx = pm[r][0];
+#pragma unroll
+        for (int e = 1; e < P; ++e) mx = max(mx, pm[r][e]);
+        int Ex = (int)(mx >> 23);
+        Ex = Ex < 1 ? 1 : (Ex > 254 ? 254 : Ex);
+        if (c == 0) es[r] = Ex;
+        int d[4][3];
+        q_digits(q_value_dev(v[i].x, Ex), d[0][0], d[0][1], d[0][2]);
+        q_digits(q_value_dev(v[i].y, Ex), d[1][0], d[1][1], d[1][2]);
+        q_digits(q_value_dev(v[i].z, Ex), d[2][0], d[2][1], d[2][2]);
+        q_digits(q_value_dev(v[i].w, Ex), d[3][0], d[3][1], d[3][2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<unsigned *>(dq + (p * 16 + r) * DS + 4 * c) =
+                (unsigned)(d[0][p] & 255) | ((unsigned)(d[1][p] & 255) << 8) | ((unsigned)(d[2][p] & 255) << 16) | ((unsigned)(d[3][p] & 255) << 24);
+    }
+    __syncthreads();
+    v4i acc[5];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) acc[s5] = (v4i){0, 0, 0, 0};
+    const int8_t *ab = dq + (lane & 15) * DS + 16 * kq;
+#pragma unroll
+    for (int h0 = 0; h0 < NS; h0 += HS) {
+        if (h0 > 0) {  // the second half's weight fragments (K = 1024)
+#pragma unroll
+            for (int st = 0; st < HS; ++st)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[st][p] = *reinterpret_cast<const v4i *>(wb + p * planeB + 64 * (h0 + st));
+        }
+#pragma unroll
+        for (int st = 0; st < HS; ++st) {
+            v4i af[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const v4i *>(ab + p * 16 * DS + 64 * (h0 + st));
+            acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0], bf[st][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0], bf[st][1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0], bf[st][2], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1], bf[st][2], acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2], bf[st][2], acc[4], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1], bf[st][0], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1], bf[st][1], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2], bf[st][1], acc[3], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[2], bf[st][0], acc[2], 0, 0, 0);
+        }
+    }
+    // C layout of 16x16: column lane & 15, rows 4 (lane >> 4) + t
+    const int eb = Eb[ncol] - 296;
+    const float bv = bias[ncol];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = 4 * kq + t, row = row0 + r;
+        const double hi = fma((double)acc[4][t], 65536.0, fma((double)acc[3][t], 256.0, (double)acc[2][t]));
+        const double lo = fma((double)acc[1][t], 256.0, (double)acc[0][t]);
+        const double x = fma(hi, 65536.0, lo);
+        float val = (float)ldexp(x, es[r] + eb) + bv;
+        if (RELU) val = val > 0.0f ? val : 0.0f;
+        if (row < M) C[(size_t)row * N + ncol] = val;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -3336,6 +3441,8 @@ static int launch_gemm(const float *A, const float *Bw, const float *Bq, const f
     return AZ_EINVAL;
 }
 
+#define QD_SMALL_MAX 512  // rows up to which the one-launch small-batch kernel serves a fixed-point dense layer
+
 template <int NWM, int NWN, int WM, int WN>
 static int qgemm_go(az_net *n, int layer, int B, const int *dyn, hipStream_t st) {
     constexpr int lds = qgemm_lds_bytes<NWM, NWN, WM, WN>(), BM = NWM * WM * 32, BN = NWN * WN * 32;
@@ -3355,6 +3462,21 @@ static int qgemm_go(az_net *n, int layer, int B, const int *dyn, hipStream_t st)
 // fc1 / fc2 in the exact block-fixed-point form: quantise the rows of the layer's input, then the int8 GEMM
 static int launch_qdense(az_net *n, int layer, int B, const int *dyn, hipStream_t st) {
     const int K = layer == 1 ? n->FIN : n->F1, N = layer == 1 ? n->F1 : n->F2;
+    static int small_max = -2;  // AZ_QD_SMALL_MAX: row limit of the one-launch small-batch kernel (0: never)
+    if (small_max == -2) { const char *e = getenv("AZ_QD_SMALL_MAX"); small_max = e ? atoi(e) : QD_SMALL_MAX; }
+    if (B <= small_max && N % 64 == 0 && (K == 128 || K == 512 || K == 1024)) {
+        const float *x = layer == 1 ? n->feat : n->h1;
+        const int8_t *w = layer == 1 ? n->qd_w1 : n->qd_w2;
+        const int *e = layer == 1 ? n->qd_e1 : n->qd_e2;
+        const float *bias = layer == 1 ? n->fc1b : n->fc2b;
+        float *out = layer == 1 ? n->h1 : n->h2;
+        const dim3 grid((unsigned)(N / 64), (unsigned)((B + 15) / 16));
+        g_last_gemm_small = 1;
+        if (K == 128) AZ_LAUNCH((k_qdense_small<128, true>), grid, dim3(256), 0, st, x, w, (size_t)N * K, e, bias, out, B, N, dyn);
+        else if (K == 512) AZ_LAUNCH((k_qdense_small<512, true>), grid, dim3(256), 0, st, x, w, (size_t)N * K, e, bias, out, B, N, dyn);
+        else AZ_LAUNCH((k_qdense_small<1024, true>), grid, dim3(256), 0, st, x, w, (size_t)N * K, e, bias, out, B, N, dyn);
+        return AZ_OK;
+    }
     hipLaunchKernelGGL(k_q_rows, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, layer == 1 ? n->feat : n->h1, B, K, dyn, n->qd_a, n->qd_rows * (size_t)K, n->qd_ea);
     static int cfg = -1;  // AZ_QG_CFG: tile plan for A/B runs (every plan gives the same bits)
     if (cfg < 0) { const char *e = getenv("AZ_QG_CFG"); cfg = e ? atoi(e) : 0; }
@@ -3639,7 +3761,7 @@ extern "C" int az_net_stage_kernel(const az_net *n, int stage, int B, char *buf,
         name = (tuned && !trunk_v1() && B >= 4096) ? (use_wino(n->CH, n->CW) ? "k_trunk2<Winograd conv2>" : "k_trunk2") : ((tuned && B <= trunk_q_max()) ? "k_trunk_q" : "k_trunk");
     }
     else if (stage == 3) name = (B <= heads_small_max(n) && n->NH <= 128 && n->F2 % 32 == 0) ? "k_heads_small" : (n->F2 == 512 ? "k_heads2" : "k_heads");
-    else if (n->qd_on) name = "k_qgemm";
+    else if (n->qd_on) name = B <= QD_SMALL_MAX ? "k_qdense_small" : "k_qgemm";
     else {
         const int N = stage == 1 ? n->F1 : n->F2, K = stage == 1 ? n->FIN : n->F1;
         switch (gemm_kind(B, N, K, (stage == 1 ? n->fc1wq : n->fc2wq) != nullptr)) {
