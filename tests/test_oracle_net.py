@@ -37,6 +37,22 @@ def test_known_answers(tag):
     assert np.abs(v[:k].astype(np.float64) * fx["players"][:k] - fx["eval_v"]).max() < TOL
 
 
+@pytest.mark.parametrize("tag", ["othello8", "othello6"])
+def test_known_answers_in_the_fixed_point_dense_form(tag):
+    """the same G2 fixtures (the reference's torch forward under closed-form weights) with fc1 / fc2 as exact block-fixed-point integer
+    dot products (AZ_DENSE_I8, oracle/az_oracle.c dense_layer_q): the form is pinned to the reference by the same 1e-5"""
+    fx = golden(f"net_{tag}.npz")
+    net = oracle_net(tag, fx)
+    net.set_qdense(True)
+    assert net.qdense()
+    canon = fx["grids"].astype(np.float32) * fx["players"].astype(np.float32)[:, None, None]
+    probs, v = net.forward(canon)
+    assert np.abs(probs - fx["probs"]).max() < TOL and np.abs(v - fx["v"]).max() < TOL
+    net.set_qdense(False)
+    p0, v0 = net.forward(canon)
+    assert np.abs(probs - p0).max() < 2e-6 and np.abs(v - v0).max() < 2e-6  # and within rounding of the fma-chain form
+
+
 def test_param_counts():
     # report p.7 Table 2 / SURVEY 6.1
     assert int(golden("net_othello8.npz")["n_params"]) == 1115362
