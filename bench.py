@@ -19,7 +19,9 @@ everything that has to survive there is a FLAT scalar inside `config` / `rooflin
   config.config4_*     BASELINE.json configs[3]: Connect4 6x7, 8192 concurrent games, 200 sims/move, at its literal size
   config.config1_*     BASELINE.json configs[0]: 2 TicTacToe rollout-MCTS games (device MCTSPlayer; the oracle's time is in cpu_baseline)
   config.config3_*     N > 1 and 32768 / N != 4096: configs[2] at its literal TOTAL (32768 games sharded N ways)
-The full objects (`saturated`, `config4`, `config1`, `config3`, `config5`, `latency`, `tree_hbm`) follow as top-level extras.
+  config.dense_i8_prototype_*  N = 1: the headline and the saturated workload once more under AZ_DENSE_I8=1 (OthelloNet's dense layers as exact
+                       block-fixed-point GEMMs on the int8 matrix pipe; child processes; a prototype, never `value`)
+The full objects (`saturated`, `config4`, `config1`, `config3`, `config5`, `latency`, `dense_i8_prototype`, `tree_hbm`) follow as top-level extras.
 
 How to read `roofline` (every field can be recomputed from profiles/ + the fields beside it):
   kernel            the kernel with the largest share of the profiled step's network time; fc1 and fc2 are ONE kernel (two launches
@@ -687,6 +689,33 @@ def run_config1(sims=100, games=2):
             "reference_seconds": [0.159, 0.171], "reference_where": "build container, 1 core (BASELINE.md section 2)"}
 
 
+def run_dense_i8_prototype(sims, sizes=(4096, 32768)):
+    """the headline workload once more with OthelloNet's dense layers on the int8 matrix pipe (AZ_DENSE_I8=1, DESIGN section 10: prototype,
+    default off).  Product and oracle read the switch once per process, so every size runs in a child process of this one (two
+    timed waves after one warm-up wave); a failing child is recorded, it does not fail the bench.  NOT the line of record."""
+    import subprocess
+    out = {"what": "AZ_DENSE_I8=1: fc1 / fc2 as exact block-fixed-point integer GEMMs (k_q_rows + k_qgemm / k_qdense_small); child processes of this bench",
+           "sizes": {}}
+    env = dict(os.environ, AZ_DENSE_I8="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for g in sizes:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--games", str(g), "--sims", str(sims), "--steps", "2", "--warmup", "1",
+               "--no-cpu-baseline", "--no-literal-configs"]
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                out["sizes"][str(g)] = {"error": (p.stderr or p.stdout)[-300:]}
+                continue
+            d = json.loads(lines[-1])
+            out["sizes"][str(g)] = {"games_per_sec": d["value"], "us_per_lockstep": d["config"]["us_per_lockstep"], "examples_per_sec": d["examples_per_sec"],
+                                    "dense_layers": d["config"].get("dense_layers"), "full_batch_launch_ms": d["roofline"].get("full_batch_launch_ms")}
+        except Exception as e:  # noqa: BLE001 -- an extra must never take the line of record down
+            out["sizes"][str(g)] = {"error": repr(e)[:300]}
+    return out
+
+
 def run_saturated(job, games, sims, steps, warmup, first_wave):
     """the headline's workload at `games` concurrent games per GPU (weak scaling at N > 1, all-gather included): where the
     rate-against-batch curve has flattened"""
@@ -721,6 +750,7 @@ def main():
     ap.add_argument("--config5-eval-episodes", type=int, default=64)
     ap.add_argument("--config5-variants", default="", help="comma-separated subset of the config5 variants (default: all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-i8", action="store_true", help="skip the AZ_DENSE_I8=1 prototype runs (child processes)")
     ap.add_argument("--no-literal-configs", action="store_true", help="skip the saturated / config1 / config3 / config4 / config5 / latency objects")
     args = ap.parse_args()
 
@@ -816,7 +846,7 @@ def main():
     if world > 1:
         dist.barrier()
     t_lap = lap("headline_profiled_step", t_lap)
-    saturated = config1 = config3 = config4 = config5 = latency = None
+    saturated = config1 = config3 = config4 = config5 = latency = dense_i8 = None
     if not args.no_literal_configs:
         if args.saturated_games and args.saturated_games != args.games:
             saturated = run_saturated(job, args.saturated_games, args.sims, steps=2, warmup=1, first_wave=1000)
@@ -837,6 +867,9 @@ def main():
         if world == 1:
             latency = run_latency(args.sims)
             t_lap = lap("latency", t_lap)
+            if os.environ.get("AZ_DENSE_I8") != "1" and not args.no_dense_i8:
+                dense_i8 = run_dense_i8_prototype(args.sims, sizes=(args.games, args.saturated_games) if args.saturated_games else (args.games,))
+                t_lap = lap("dense_i8_prototype", t_lap)
     if rank == 0:
         cfg = out["config"]
         cfg["end_to_end_frac"] = roof.get("end_to_end_frac")
@@ -861,6 +894,11 @@ def main():
                 cfg.update({"config5_10_epochs_iteration_seconds": v10["iterations"][1]["iteration_seconds"],
                             "config5_10_epochs_sgd_share": v10["iterations"][1]["sgd_share"],
                             "config5_10_epochs_sgd_ms_per_step": v10["iterations"][1]["sgd_ms_per_step"]})
+        if dense_i8 is not None:
+            for g, key in ((args.games, "dense_i8_prototype_games_per_sec"), (args.saturated_games, "dense_i8_prototype_saturated_games_per_sec")):
+                v = dense_i8["sizes"].get(str(g), {})
+                if "games_per_sec" in v:
+                    cfg[key] = v["games_per_sec"]
         cfg["timed_region"] = "engine as shipped: HIP-graph replays, no event recording"
         cfg["dense_layers"] = ("exact block-fixed-point on the int8 matrix pipe (AZ_DENSE_I8=1: the roofline's f32 MFMA peak does not price fc1 / fc2)"
                                if os.environ.get("AZ_DENSE_I8") == "1" else "float32 fma chains on the f32-input MFMA")
@@ -879,7 +917,7 @@ def main():
         tree["k_step_source"] = kwhy
         out["tree_hbm"] = tree
         for name, obj in (("saturated", saturated), ("config1", config1), ("config3", config3), ("config4", config4), ("config5", config5),
-                          ("latency", latency), ("cpu_baseline", cpu)):
+                          ("latency", latency), ("dense_i8_prototype", dense_i8), ("cpu_baseline", cpu)):
             if obj is not None:
                 out[name] = obj
         phases["total"] = round(time.perf_counter() - t_start, 2)
