@@ -703,7 +703,7 @@ def run_dense_i8_prototype(sims, sizes=(4096, 32768)):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--games", str(g), "--sims", str(sims), "--steps", "2", "--warmup", "1",
                "--no-cpu-baseline", "--no-literal-configs"]
         try:
-            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
             lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not lines:
                 out["sizes"][str(g)] = {"error": (p.stderr or p.stdout)[-300:]}
