@@ -36,3 +36,14 @@ def test_cpu_share_names_its_source():
 def test_stage_flops_are_the_surveys():
     assert sum(bench.stage_flops(8, 8, 1024, 512, 65)) == 4339712  # OthelloNet 8x8
     assert sum(bench.stage_flops(7, 6, 64, 32, 7)) == 1306752      # Connect4Net
+
+
+def test_a_failing_prototype_child_is_recorded_and_does_not_fail_the_bench():
+    """run_dense_i8_prototype starts bench.py once more per size in a child process with AZ_DENSE_I8=1; without a GPU the child cannot
+    run -- the extra must come back with the error in it instead of raising (it must never take the line of record down)"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU")
+    out = bench.run_dense_i8_prototype(sims=4, sizes=(8,))
+    assert set(out["sizes"]) == {"8"} and "error" in out["sizes"]["8"] and "games_per_sec" not in out["sizes"]["8"]
