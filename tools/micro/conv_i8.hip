@@ -138,6 +138,96 @@ __global__ __launch_bounds__(256) void k_conv_i8(const int8_t *__restrict__ in, 
     }
 }
 
+// The same layer with ONE board per wave and eight waves per workgroup (two per SIMD): one wave's epilogue (VALU: float64 combination,
+// re-quantisation) runs under the other wave's MFMAs.  in / out as above, a "pair" being two consecutive boards.
+__global__ __launch_bounds__(512) void k_conv_i8_w8(const int8_t *__restrict__ in, const int *__restrict__ ein, const int8_t *__restrict__ w, const int *__restrict__ ew,
+                                                    const float *__restrict__ bias, int8_t *__restrict__ out, int *__restrict__ eout, int n_pairs, int reps) {
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    int8_t *ws = lds;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    constexpr int BP = SLOTS * NCH;              // bytes of one digit plane of ONE board
+    int8_t *ai = lds + W_BYTES + wave * 6 * BP;  // [3][SLOTS][32] in, then the same out
+    int8_t *ao = ai + 3 * BP;
+    for (int i = tid; i < W_BYTES / 16; i += 512) reinterpret_cast<int4 *>(ws)[i] = reinterpret_cast<const int4 *>(w)[i];
+    __syncthreads();
+    for (int board = blockIdx.x * 8 + wave; board < 2 * n_pairs; board += gridDim.x * 8) {
+        const int pair = board >> 1, bd = board & 1;
+        for (int p = 0; p < 3; ++p)
+            for (int i = lane; i < BP / 16; i += 64)
+                reinterpret_cast<int4 *>(ai + p * BP)[i] = reinterpret_cast<const int4 *>(in + (size_t)pair * ACT_BYTES + p * ACT_PLANE + bd * BP)[i];
+        const int e0 = ein[board];
+        for (int rep = 0; rep < reps; ++rep) {
+            v16i acc[2][5];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int s = 0; s < 5; ++s)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc[jj][s][t] = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                v4i a[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v4i *>(ws + ((tap * 3 + p) * NCH + r) * NCH + 16 * h);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int pos = 32 * jj + r, y = (pos >> 3) + dy, x = (pos & 7) + dx;
+                    const int sp = (y >= 0 && y < 8 && x >= 0 && x < 8) ? y * 8 + x : P;
+                    v4i b[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const v4i *>(ai + p * BP + sp * NCH + 16 * h);
+#define PAIR(PA, PB) acc[jj][PA + PB] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[PA], b[PB], acc[jj][PA + PB], 0, 0, 0);
+                    PAIR(0, 0) PAIR(0, 1) PAIR(0, 2) PAIR(1, 2) PAIR(2, 2) PAIR(1, 0) PAIR(1, 1) PAIR(2, 1) PAIR(2, 0)
+#undef PAIR
+                }
+            }
+            float v[2][16];
+            unsigned mx = 0;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int oc = (t & 3) + 8 * (t >> 2) + 4 * h;
+                    const double hi = fma((double)acc[jj][4][t], 65536.0, fma((double)acc[jj][3][t], 256.0, (double)acc[jj][2][t]));
+                    const double lo = fma((double)acc[jj][1][t], 256.0, (double)acc[jj][0][t]);
+                    float val = (float)ldexp(fma(hi, 65536.0, lo), e0 + ew[oc] - 296) + bias[oc];
+                    val = val > 0.0f ? val : 0.0f;
+                    v[jj][t] = val;
+                    unsigned bits;
+                    memcpy(&bits, &val, 4);
+                    mx = max(mx, bits);
+                }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+            int E = (int)(mx >> 23);
+            E = E < 1 ? 1 : (E > 254 ? 254 : E);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int pos = 32 * jj + r;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned wd[3] = {0, 0, 0};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        int d0, d1, d2;
+                        q_digits(q_value(v[jj][4 * g + k], E), d0, d1, d2);
+                        wd[0] |= (unsigned)(d0 & 255) << (8 * k); wd[1] |= (unsigned)(d1 & 255) << (8 * k); wd[2] |= (unsigned)(d2 & 255) << (8 * k);
+                    }
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned *>(ao + p * BP + pos * NCH + 8 * g + 4 * h) = wd[p];
+                }
+            }
+            if (lane == 0 && rep == reps - 1) eout[board] = E;
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+        if (lane < 6) *reinterpret_cast<int4 *>(ao + (lane / 2) * BP + P * NCH + 16 * (lane % 2)) = make_int4(0, 0, 0, 0);
+        for (int p = 0; p < 3; ++p)
+            for (int i = lane; i < BP / 16; i += 64)
+                reinterpret_cast<int4 *>(out + (size_t)pair * ACT_BYTES + p * ACT_PLANE + bd * BP)[i] = reinterpret_cast<const int4 *>(ao + p * BP)[i];
+    }
+}
+
 int main() {
     const int n_pairs = 4096, reps_timed = 64;
     srand(1);
@@ -186,7 +276,14 @@ int main() {
     hipMemcpy(d_bias, bias.data(), NCH * 4, hipMemcpyHostToDevice);
     const int lds = W_BYTES + 4 * 2 * ACT_BYTES;
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_i8), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k_conv_i8, dim3(256), dim3(256), lds, 0, d_in, d_ein, d_w, d_ew, d_bias, d_out, d_eout, n_pairs, 1);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_i8_w8), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    for (int variant = 0; variant < 2; ++variant) {
+    printf("== %s\n", variant == 0 ? "one board pair per wave, four waves per workgroup" : "one board per wave, eight waves per workgroup (two per SIMD)");
+    hipMemset(d_out, 0x55, in.size());
+#define LAUNCH(np_, reps_)                                                                                                       \
+    if (variant == 0) hipLaunchKernelGGL(k_conv_i8, dim3(256), dim3(256), lds, 0, d_in, d_ein, d_w, d_ew, d_bias, d_out, d_eout, np_, reps_); \
+    else hipLaunchKernelGGL(k_conv_i8_w8, dim3(256), dim3(512), lds, 0, d_in, d_ein, d_w, d_ew, d_bias, d_out, d_eout, np_, reps_);
+    LAUNCH(n_pairs, 1)
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
     std::vector<int8_t> out(in.size()); std::vector<int> eout(ein.size());
     hipMemcpy(out.data(), d_out, out.size(), hipMemcpyDeviceToHost); hipMemcpy(eout.data(), d_eout, eout.size() * 4, hipMemcpyDeviceToHost);
@@ -219,10 +316,10 @@ int main() {
     printf("check: %lld digits of %d boards compared with the CPU restatement, %lld differ\n", checked, 2 * ((n_pairs + 96) / 97), bad);
     hipEvent_t t0, t1; hipEventCreate(&t0); hipEventCreate(&t1);
     for (int np : {1024, 2048, 4096}) {  // 1, 2, 4 pairs per wave on 1024 waves
-        hipLaunchKernelGGL(k_conv_i8, dim3(256), dim3(256), lds, 0, d_in, d_ein, d_w, d_ew, d_bias, d_out, d_eout, np, 4);
+        LAUNCH(np, 4)
         hipDeviceSynchronize();
         hipEventRecord(t0);
-        hipLaunchKernelGGL(k_conv_i8, dim3(256), dim3(256), lds, 0, d_in, d_ein, d_w, d_ew, d_bias, d_out, d_eout, np, reps_timed);
+        LAUNCH(np, reps_timed)
         hipEventRecord(t1); hipEventSynchronize(t1);
         float ms; hipEventElapsedTime(&ms, t0, t1);
         const double layers = (double)np * reps_timed;  // layer-pairs executed
@@ -231,5 +328,7 @@ int main() {
         printf("%d pairs x %d layers: %.3f ms = %.2f us per layer and board pair (= %.1f K cycles at 2.4 GHz; 324 MFMAs are 10.4 K; a direct f32 layer of k_trunk2 takes ~23 K)\n",
                np, reps_timed, ms, us, us * 2.4);
     }
-    return bad ? 1 : 0;
+    if (bad) return 1;
+    }
+    return 0;
 }
