@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void k_conv_i8(const int8_t *__restrict__ in, 
 
 // The same layer with ONE board per wave and eight waves per workgroup (two per SIMD): one wave's epilogue (VALU: float64 combination,
 // re-quantisation) runs under the other wave's MFMAs.  in / out as above, a "pair" being two consecutive boards.
+template <bool INTQ>
 __global__ __launch_bounds__(512) void k_conv_i8_w8(const int8_t *__restrict__ in, const int *__restrict__ ein, const int8_t *__restrict__ w, const int *__restrict__ ew,
                                                     const float *__restrict__ bias, int8_t *__restrict__ out, int *__restrict__ eout, int n_pairs, int reps) {
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
@@ -185,40 +186,95 @@ __global__ __launch_bounds__(512) void k_conv_i8_w8(const int8_t *__restrict__ i
 #undef PAIR
                 }
             }
-            float v[2][16];
-            unsigned mx = 0;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+            int E;
+            if constexpr (!INTQ) {
+                float v[2][16];
+                unsigned mx = 0;
+    #pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+    #pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int oc = (t & 3) + 8 * (t >> 2) + 4 * h;
+                        const double hi = fma((double)acc[jj][4][t], 65536.0, fma((double)acc[jj][3][t], 256.0, (double)acc[jj][2][t]));
+                        const double lo = fma((double)acc[jj][1][t], 256.0, (double)acc[jj][0][t]);
+                        float val = (float)ldexp(fma(hi, 65536.0, lo), e0 + ew[oc] - 296) + bias[oc];
+                        val = val > 0.0f ? val : 0.0f;
+                        v[jj][t] = val;
+                        unsigned bits;
+                        memcpy(&bits, &val, 4);
+                        mx = max(mx, bits);
+                    }
+    #pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+                E = (int)(mx >> 23);
+                E = E < 1 ? 1 : (E > 254 ? 254 : E);
+    #pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int pos = 32 * jj + r;
+    #pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        unsigned wd[3] = {0, 0, 0};
+    #pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            int d0, d1, d2;
+                            q_digits(q_value(v[jj][4 * g + k], E), d0, d1, d2);
+                            wd[0] |= (unsigned)(d0 & 255) << (8 * k); wd[1] |= (unsigned)(d1 & 255) << (8 * k); wd[2] |= (unsigned)(d2 & 255) << (8 * k);
+                        }
+    #pragma unroll
+                        for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned *>(ao + p * BP + pos * NCH + 8 * g + 4 * h) = wd[p];
+                    }
+                }
+
+            } else {
+                // integer re-quantisation: Y = max(X + B, 0) with the bias at the accumulator's scale (value = Y 2^s, s = e + ew[oc] - 296);
+                // the board's next exponent from the exact leading bit; q' = Y 2^(s + 148 - E') rounded to nearest even by one shift
+                long long Bq[16];
+                int soc[16];
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const int oc = (t & 3) + 8 * (t >> 2) + 4 * h;
-                    const double hi = fma((double)acc[jj][4][t], 65536.0, fma((double)acc[jj][3][t], 256.0, (double)acc[jj][2][t]));
-                    const double lo = fma((double)acc[jj][1][t], 256.0, (double)acc[jj][0][t]);
-                    float val = (float)ldexp(fma(hi, 65536.0, lo), e0 + ew[oc] - 296) + bias[oc];
-                    val = val > 0.0f ? val : 0.0f;
-                    v[jj][t] = val;
-                    unsigned bits;
-                    memcpy(&bits, &val, 4);
-                    mx = max(mx, bits);
+                    soc[t] = e0 + ew[oc] - 296;
+                    Bq[t] = (long long)rint(ldexp((double)bias[oc], -soc[t]));
                 }
+                int mxe = -100000;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-            int E = (int)(mx >> 23);
-            E = E < 1 ? 1 : (E > 254 ? 254 : E);
+                for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int pos = 32 * jj + r;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    unsigned wd[3] = {0, 0, 0};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        int d0, d1, d2;
-                        q_digits(q_value(v[jj][4 * g + k], E), d0, d1, d2);
-                        wd[0] |= (unsigned)(d0 & 255) << (8 * k); wd[1] |= (unsigned)(d1 & 255) << (8 * k); wd[2] |= (unsigned)(d2 & 255) << (8 * k);
+                    for (int t = 0; t < 16; ++t) {
+                        long long X = (long long)acc[jj][0][t] + ((long long)acc[jj][1][t] << 8) + ((long long)acc[jj][2][t] << 16) + ((long long)acc[jj][3][t] << 24) +
+                                      ((long long)acc[jj][4][t] << 32);
+                        long long Y = X + Bq[t];
+                        if (Y > 0) mxe = max(mxe, 63 - __clzll(Y) + soc[t]);
                     }
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned *>(ao + p * BP + pos * NCH + 8 * g + 4 * h) = wd[p];
+                for (int o = 32; o >= 1; o >>= 1) mxe = max(mxe, __shfl_xor(mxe, o));
+                E = mxe + 127;
+                E = E < 1 ? 1 : (E > 254 ? 254 : E);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int pos = 32 * jj + r;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        unsigned wd[3] = {0, 0, 0};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int t = 4 * g + kk;
+                            long long X = (long long)acc[jj][0][t] + ((long long)acc[jj][1][t] << 8) + ((long long)acc[jj][2][t] << 16) + ((long long)acc[jj][3][t] << 24) +
+                                          ((long long)acc[jj][4][t] << 32);
+                            long long Y = X + Bq[t];
+                            Y = Y > 0 ? Y : 0;
+                            const int sh = E - 148 - soc[t];
+                            int q;
+                            if (sh >= 63) q = 0;
+                            else if (sh > 0) q = (int)((Y + ((1ll << (sh - 1)) - 1 + ((Y >> sh) & 1))) >> sh);
+                            else q = (int)(Y << (-sh));
+                            int d0, d1, d2;
+                            q_digits(q, d0, d1, d2);
+                            wd[0] |= (unsigned)(d0 & 255) << (8 * kk); wd[1] |= (unsigned)(d1 & 255) << (8 * kk); wd[2] |= (unsigned)(d2 & 255) << (8 * kk);
+                        }
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned *>(ao + p * BP + pos * NCH + 8 * g + 4 * h) = wd[p];
+                    }
                 }
             }
             if (lane == 0 && rep == reps - 1) eout[board] = E;
@@ -279,23 +335,24 @@ int main() {
     hipMemcpy(d_bias, bias.data(), NCH * 4, hipMemcpyHostToDevice);
     const int lds = W_BYTES + 4 * 2 * ACT_BYTES;
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_i8), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_i8_w8), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    for (int variant = 0; variant < 2; ++variant) {
-    printf("== %s\n", variant == 0 ? "one board pair per wave, four waves per workgroup" : "one board per wave, eight waves per workgroup (two per SIMD)");
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_i8_w8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_i8_w8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    for (int variant = 0; variant < 3; ++variant) {
+    printf("== %s\n", variant == 0 ? "one board pair per wave, four waves per workgroup" : (variant == 1 ? "one board per wave, eight waves per workgroup (two per SIMD)" : "the same with the integer re-quantisation epilogue (its own specification, restated on the CPU)"));
     hipMemset(d_out, 0x55, in.size());
 #define LAUNCH(np_, reps_)                                                                                                       \
     if (variant == 0) hipLaunchKernelGGL(k_conv_i8, dim3(256), dim3(256), lds, 0, d_in, d_ein, d_w, d_ew, d_bias, d_out, d_eout, np_, reps_); \
-    else hipLaunchKernelGGL(k_conv_i8_w8, dim3(256), dim3(512), lds, 0, d_in, d_ein, d_w, d_ew, d_bias, d_out, d_eout, np_, reps_);
+    else if (variant == 1) hipLaunchKernelGGL(k_conv_i8_w8<false>, dim3(256), dim3(512), lds, 0, d_in, d_ein, d_w, d_ew, d_bias, d_out, d_eout, np_, reps_); \
+    else hipLaunchKernelGGL(k_conv_i8_w8<true>, dim3(256), dim3(512), lds, 0, d_in, d_ein, d_w, d_ew, d_bias, d_out, d_eout, np_, reps_);
     LAUNCH(n_pairs, 1)
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
     std::vector<int8_t> out(in.size()); std::vector<int> eout(ein.size());
     hipMemcpy(out.data(), d_out, out.size(), hipMemcpyDeviceToHost); hipMemcpy(eout.data(), d_eout, eout.size() * 4, hipMemcpyDeviceToHost);
-    // CPU restatement on a sample of pairs: exact integer convolution, the same conversions
+    // CPU restatement on a sample of pairs: exact integer convolution, the same conversions (variant 2: the integer re-quantisation)
     long long bad = 0, checked = 0;
     for (int pr = 0; pr < n_pairs; pr += 97)
         for (int b = 0; b < 2; ++b) {
-            std::vector<float> v(P * NCH);
-            float m = 0;
+            std::vector<long long> Xs(P * NCH);
             for (int pos = 0; pos < P; ++pos) for (int oc = 0; oc < NCH; ++oc) {
                 long long X = 0;
                 for (int t = 0; t < 9; ++t) {
@@ -304,15 +361,40 @@ int main() {
                     const int *a = &inq[(((size_t)pr * 2 + b) * P + y * 8 + x) * NCH], *ww = &wq[(t * NCH + oc) * NCH];
                     for (int ic = 0; ic < NCH; ++ic) X += (long long)a[ic] * ww[ic];
                 }
-                float val = (float)ldexp((double)X, ein[2 * pr + b] + ew[oc] - 296) + bias[oc];
-                val = val > 0.f ? val : 0.f;
-                v[pos * NCH + oc] = val; m = fmaxf(m, val);
+                Xs[pos * NCH + oc] = X;
             }
-            uint32_t bb; memcpy(&bb, &m, 4);
-            int E = (int)(bb >> 23); E = E < 1 ? 1 : (E > 254 ? 254 : E);
+            std::vector<int> qn(P * NCH);
+            int E;
+            if (variant < 2) {
+                std::vector<float> v(P * NCH);
+                float m = 0;
+                for (int pos = 0; pos < P; ++pos) for (int oc = 0; oc < NCH; ++oc) {
+                    float val = (float)ldexp((double)Xs[pos * NCH + oc], ein[2 * pr + b] + ew[oc] - 296) + bias[oc];
+                    val = val > 0.f ? val : 0.f;
+                    v[pos * NCH + oc] = val; m = fmaxf(m, val);
+                }
+                uint32_t bb; memcpy(&bb, &m, 4);
+                E = (int)(bb >> 23); E = E < 1 ? 1 : (E > 254 ? 254 : E);
+                for (int i = 0; i < P * NCH; ++i) qn[i] = q_value(v[i], E);
+            } else {
+                std::vector<long long> Y(P * NCH);
+                int mxe = -100000;
+                for (int pos = 0; pos < P; ++pos) for (int oc = 0; oc < NCH; ++oc) {
+                    const int so = ein[2 * pr + b] + ew[oc] - 296;
+                    long long y = Xs[pos * NCH + oc] + (long long)rint(ldexp((double)bias[oc], -so));
+                    if (y > 0) { const int fl = 63 - __builtin_clzll((unsigned long long)y) + so; mxe = fl > mxe ? fl : mxe; }
+                    Y[pos * NCH + oc] = y > 0 ? y : 0;
+                }
+                E = mxe + 127; E = E < 1 ? 1 : (E > 254 ? 254 : E);
+                for (int pos = 0; pos < P; ++pos) for (int oc = 0; oc < NCH; ++oc) {
+                    const int so = ein[2 * pr + b] + ew[oc] - 296, sh = E - 148 - so;
+                    const long long y = Y[pos * NCH + oc];
+                    qn[pos * NCH + oc] = sh >= 63 ? 0 : (sh > 0 ? (int)((y + ((1ll << (sh - 1)) - 1 + ((y >> sh) & 1))) >> sh) : (int)(y << (-sh)));
+                }
+            }
             if (E != eout[2 * pr + b]) ++bad;
             for (int pos = 0; pos < P; ++pos) for (int oc = 0; oc < NCH; ++oc) {
-                int d[3]; q_digits(q_value(v[pos * NCH + oc], E), d[0], d[1], d[2]);
+                int d[3]; q_digits(qn[pos * NCH + oc], d[0], d[1], d[2]);
                 for (int p = 0; p < 3; ++p) { ++checked; if (out[(size_t)pr * ACT_BYTES + p * ACT_PLANE + (b * SLOTS + pos) * NCH + oc] != (int8_t)d[p]) ++bad; }
             }
         }
