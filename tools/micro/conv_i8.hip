@@ -8,9 +8,10 @@
 //   are packed in-lane (no cross-lane traffic) and written as dwords.
 // Per layer and pair: 9 taps x 4 position tiles x 9 digit pairs = 324 MFMAs, five int32 accumulators per tile; the board's next
 // exponent is a wave-local maximum.  The output digits + exponents are checked against a CPU restatement (exact integers).
-// Two variants: a board pair per wave at one wave per SIMD (k_conv_i8), one board per wave at two waves per SIMD (k_conv_i8_w8: one wave's
-// epilogue runs under the other's MFMAs).  MI355X: 11.6 / 8.9 us per layer and board pair (the 324 MFMAs alone: 4.3 us); the float64
-// combination + re-quantisation of the epilogue is what bounds both (profiles/r04_micro_conv_i8.txt).
+// Three variants: a board pair per wave at one wave per SIMD (k_conv_i8), one board per wave at two waves per SIMD (k_conv_i8_w8<false>: one
+// wave's epilogue runs under the other's MFMAs), and the latter with an all-integer re-quantisation (k_conv_i8_w8<true>, its own
+// specification).  MI355X: 11.5 / 8.8 / 11.6 us per layer and board pair (the 324 MFMAs alone: 4.3 us): the epilogue bounds all three, and
+// 64-bit integer arithmetic is no cheaper than the float64 combination (profiles/r04_micro_conv_i8.txt).
 // build + run on the GPU box: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o /tmp/conv_i8 tools/micro/conv_i8.hip && /tmp/conv_i8
 #include <hip/hip_runtime.h>
 #include <cmath>
