@@ -17,7 +17,9 @@ class Arena:
         self.player1, self.player2, self.board = player1, player2, board
         self.game = board.game
 
-    def play_game(self, player2_starts=False, return_results=False, verbose=False, **_display_kwargs):
+    def play_game(self, player2_starts=False, display=False, save_frames=False, return_results=False, show_indexes=True, show_probs=False, verbose=False):
+        """arena.py:36-117, positional order included; `display`, `save_frames`, `show_indexes`, `show_probs` steer the board rendering
+        of the reference (out of scope here): accepted and ignored"""
         idx = 1 if player2_starts else 0
         self.board.reset()
         self.player1.reset()

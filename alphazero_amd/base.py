@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 DEFAULT_MODELS_PATH = os.path.join(os.getcwd(), "models/")
+DEFAULT_CONFIGS_PATH = os.path.join(os.getcwd(), "configs/")  # utils.py:12 (there: beside the package sources)
 
 
 class dotdict(dict):
@@ -41,6 +42,12 @@ class MoveFormat(_ValueEnum):
 class TreeEval(_ValueEnum):
     ROLLOUT = "rollout"
     NEURAL = "neural"
+
+
+class DisplayMode(_ValueEnum):
+    """base.py:45-48; the modes exist so that configs and constructor calls written for the reference load; rendering itself is out of scope"""
+    HUMAN = "human"
+    PIXEL = "pixel"
 
 
 class DataTransf(_ValueEnum):
@@ -96,13 +103,51 @@ class Board:
     def __str__(self):
         return type(self).__name__
 
-    def _abstract(self, *a, **k):
+    # the abstract contract (base.py:121-198): same names, same parameters; concrete boards live in games/*
+    def reset(self):
         raise NotImplementedError
 
-    reset = clone = get_board_shape = get_n_cells = get_action_size = get_score = _abstract
-    is_legal_move = get_moves = get_random_move = play_move = is_game_over = get_winner = _abstract
+    def clone(self):
+        raise NotImplementedError
 
-    def display(self, *args, **kwargs):
+    def get_board_shape(self):
+        raise NotImplementedError
+
+    def get_n_cells(self):
+        raise NotImplementedError
+
+    def get_action_size(self):
+        raise NotImplementedError
+
+    def get_score(self):
+        raise NotImplementedError
+
+    def is_legal_move(self, move, player):
+        raise NotImplementedError
+
+    def get_moves(self, player):
+        raise NotImplementedError
+
+    def get_random_move(self, player):
+        raise NotImplementedError
+
+    def play_move(self, move):
+        raise NotImplementedError
+
+    def is_game_over(self):
+        raise NotImplementedError
+
+    def get_winner(self):
+        raise NotImplementedError
+
+    def human_display(self, *args, **kwargs):
+        raise NotImplementedError("board rendering is out of scope of the self-play engine")
+
+    def pixel_display(self, *args, **kwargs):
+        raise NotImplementedError("board rendering is out of scope of the self-play engine")
+
+    def display(self, show_indexes=True, infos=None, filename=None, mode=None):
+        """base.py:199-225 dispatches to human_display / pixel_display: rendering is out of scope here"""
         raise NotImplementedError("board rendering is out of scope of the self-play engine")
 
 
@@ -189,6 +234,19 @@ class PolicyValueNetwork(nn.Module):
         x = torch.tensor(board.player * board.grid, dtype=torch.float, device=self.device)
         p, v = self.predict(x)
         return p.cpu().numpy().reshape(-1), board.player * v.cpu().item()
+
+    # the four hooks every concrete network supplies (base.py:370-397)
+    def get_normalized_probs(self, probs, legal_moves):
+        raise NotImplementedError
+
+    def to_neural_output(self, move_probs):
+        raise NotImplementedError
+
+    def reflect_neural_output(self, neural_output, axis):
+        raise NotImplementedError
+
+    def rotate_neural_output(self, neural_output, angle):
+        raise NotImplementedError
 
     # the device side: weights of this module on the HIP engine --------------------------------
     def hip_shape(self):

@@ -10,7 +10,7 @@ import torch
 from . import base
 from .arena import Arena
 from .base import DataTransf, dotdict
-from .games.registers import BOARDS_REGISTER, CONFIGS_REGISTER, DATA_AUGMENT_STRATEGIES, NETWORKS_REGISTER
+from .games.registers import BOARDS_REGISTER, CONFIGS_REGISTER, DATA_AUGMENT_STRATEGIES, GAMES_SET, NETWORKS_REGISTER
 from .players import PLAYERS_REGISTER, PLAYERS_SET, AlphaZeroPlayer
 from .schedulers import TEMP_SCHEDULERS
 
@@ -90,12 +90,44 @@ class AlphaZeroTrainer:
             print(log)
 
     @staticmethod
+    def print_config(config, verbose=True):
+        """trainer.py:149-154"""
+        if verbose:
+            for pname, value in config.to_dict().items():
+                print(f"- {pname}: {value}")
+
+    @staticmethod
     def load_config_from_json(game, json_config_file):
         if json_config_file is None:
             return CONFIGS_REGISTER[game]()
         with open(json_config_file) as f:
             cfg = dotdict(json.load(f))
         return CONFIGS_REGISTER[cfg.game](**cfg)
+
+    @staticmethod
+    def estimate_training_duration(game, json_config_file=None):
+        """trainer.py:166-213: the duration of a training run estimated from SelfPlayTimer (10 games) and NeuralTimer (100 batches), printed
+        in the reference's five lines.  The estimate is the reference's arithmetic on this package's single-game path (timers.py); the
+        batched engine plays config.episodes games at once and is far below it (SelfPlayTimer.timeit_batched times that)."""
+        from datetime import timedelta
+
+        from .timers import NeuralTimer, SelfPlayTimer
+        config = AlphaZeroTrainer.load_config_from_json(game, json_config_file)
+        game = game if game is not None else config.game
+        if game is not None and game != config.game:
+            raise ValueError(f"Game '{game}' and game '{config.game}' in the configuration file do not match.")
+        AlphaZeroTrainer.print_config(config)
+        episode_sec, episode_steps = SelfPlayTimer(game, config).timeit(n_episodes=10)
+        batch_sec = NeuralTimer(game, config).timeit(n_batches=100)
+        self_play = config.episodes * episode_sec
+        n_samples = config.episodes * episode_steps
+        n_batches = n_samples // config.batch_size if config.batch_size < n_samples else 1
+        optim = config.epochs * batch_sec * n_batches
+        evaluation = config.eval_episodes * episode_sec if config.do_eval else 0  # the opponent approximated by an AlphaZero player
+        iteration = self_play + optim + evaluation
+        for label, sec in (("Self-play", self_play), ("Optimization", optim), ("Iteration", iteration), ("Evaluation", evaluation)):
+            print(f"{label} duration: {timedelta(seconds=round(sec))} (h:m:s)")
+        print(f"TOTAL training duration: {timedelta(seconds=round(config.iterations * iteration))} (h:m:s)")
 
     # ------------------------------------------------------------------ self-play on the engine
     def _shape(self):
@@ -476,3 +508,11 @@ class AlphaZeroTrainer:
         self.data_augment_strategy = DATA_AUGMENT_STRATEGIES[self.game] if c.data_augmentation else None
         self._init_evaluator()
         self.loss_values = {}
+
+
+def freeze_config(game=None):
+    """trainer.py:580-587: the default configuration of `game` (of every game if None) written as <game>.json under DEFAULT_CONFIGS_PATH"""
+    os.makedirs(base.DEFAULT_CONFIGS_PATH, exist_ok=True)
+    for g in ([game] if game is not None else list(GAMES_SET)):
+        with open(os.path.join(base.DEFAULT_CONFIGS_PATH, f"{g}.json"), "w") as f:
+            json.dump(AlphaZeroTrainer.load_config_from_json(g, json_config_file=None).to_dict(), f, indent=4)

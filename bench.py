@@ -13,15 +13,17 @@ value = games of all ranks / time; K steps = K waves (">= 2 waves, st
 it ships (searches replayed as HIP graphs, no event recording); the per-kernel times of the roofline come from one extra, separately
 profiled step in which every network launch carries its own start / stop events (the dispatch's begin / end timestamps).
 
-The driver's record keeps the scalar fields of `config`, `roofline` and `cpu_baseline` (nested objects and long strings are cut), so
-everything that has to survive there is a FLAT scalar inside `config` / `roofline`:
+The LAST line of stdout is the line of record and holds scalars only (`record_line`: the contract's top-level fields + flat `config`,
+`roofline`, `cpu_baseline`; < 6 KB, strict JSON, printed ONCE, nothing on stdout after it).  Every nested object -- `saturated`, `config4`,
+`config5`, `config1`, `config3`, `latency`, `tree_hbm`, the per-kernel tables of the roofline, the opt-in `dense_i8_prototype` -- goes to
+bench_detail.json beside this file (and gpurun_out/bench_detail.json); the line names it in `detail`.  Flat copies in the line:
   config.saturated_*   the same workload at 32768 concurrent games per GPU (where the rate has flattened: the chip is full)
   config.config4_*     BASELINE.json configs[3]: Connect4 6x7, 8192 concurrent games, 200 sims/move, at its literal size
-  config.config1_*     BASELINE.json configs[0]: 2 TicTacToe rollout-MCTS games (device MCTSPlayer; the oracle's time is in cpu_baseline)
+  config.config5_10_epochs_*  BASELINE.json configs[4] at the reference's own hyper-parameters (10 epochs of batch 64)
   config.config3_*     N > 1 and 32768 / N != 4096: configs[2] at its literal TOTAL (32768 games sharded N ways)
-  config.dense_i8_prototype_*  N = 1: the headline and the saturated workload once more under AZ_DENSE_I8=1 (OthelloNet's dense layers as exact
-                       block-fixed-point GEMMs on the int8 matrix pipe; child processes; a prototype, never `value`)
-The full objects (`saturated`, `config4`, `config1`, `config3`, `config5`, `latency`, `dense_i8_prototype`, `tree_hbm`) follow as top-level extras.
+Order of the run: CPU baseline (before HIP is touched) -> headline (warm-up, timed steps, one profiled step) -> saturated -> config4 ->
+config5 (ten-epoch variant) -> THE LINE -> config1, the other config5 variants, latency (detail file only).  On one GPU a failing optional
+leg is recorded in `errors` and never takes the line down.
 
 How to read `roofline` (every field can be recomputed from profiles/ + the fields beside it):
   kernel            the kernel with the largest share of the profiled step's network time; fc1 and fc2 are ONE kernel (two launches
@@ -292,6 +294,96 @@ def compact(r):
             "forward_frac": ro.get("forward_frac")}
 
 
+# ------------------------------------------------------------------------------------------------ the line of record
+# The driver parses the LAST line of stdout and stores an 8 KB tail of it: the line of record holds scalars only and stays far below that
+# (round 4's 23 KB line, nested objects included, came back unparsed).  Everything nested goes to bench_detail.json beside this file.
+LINE_BUDGET = 6144
+DETAIL_NAME = "bench_detail.json"
+TOP_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"]
+TOP_EXTRA = ["examples_per_sec", "sims_per_sec", "plies_per_game"]
+CONFIG_KEYS = ["workload", "concurrent_games_per_gpu", "games_per_gpu_per_step", "sims_per_move", "parallelism", "examples_per_sec", "us_per_lockstep",
+               "end_to_end_frac", "samples_to_host_ms_per_step", "games_per_sec_incl_host_copy",
+               "saturated_concurrent_games_per_gpu", "saturated_games_per_sec", "saturated_end_to_end_frac",
+               "config4_workload", "config4_games_per_sec", "config4_end_to_end_frac", "config4_us_per_lockstep",
+               "config3_games_per_sec", "config3_concurrent_games_per_gpu", "config3_end_to_end_frac_per_gpu",
+               "config5_10_epochs_iteration_seconds", "config5_10_epochs_sgd_share", "config5_10_epochs_sgd_ms_per_step",
+               "config1_device_seconds_game0", "config1_device_seconds_game1", "timed_region", "dense_layers"]
+ROOF_KEYS = ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_algorithmic", "end_to_end_frac", "forward_frac", "mfma_busy",
+             "avg_launch_ms", "launches", "flops_per_board", "boards_evaluated", "kernel_ms_total", "share_of_network_time", "trunk_frac", "dense_frac",
+             "heads_frac", "saturated_frac", "saturated_end_to_end_frac", "saturated_kernel", "config4_frac", "config4_end_to_end_frac", "config4_kernel",
+             "k_step_us", "k_step_traffic", "k_step_traffic_algorithmic"]
+CPU_KEYS = ["value", "unit", "cores", "kind", "sample", "cpu_model", "usable_cores", "usable_cores_source", "multi_process_count", "multi_process_games_per_sec",
+            "reference_s_per_game", "reference_where", "config1_oracle_seconds_game0", "config1_oracle_seconds_game1", "seconds"]
+
+
+def _scalar(v, cut=110):
+    """what may go into the line of record: None / bool / int / finite float (6 significant digits) / short string; else the marker _DROP"""
+    if v is None or isinstance(v, bool):
+        return v
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    if isinstance(v, (float, np.floating)):
+        v = float(v)
+        return float(f"{v:.6g}") if np.isfinite(v) else None
+    if isinstance(v, str):
+        return v[:cut]
+    return _scalar  # a nested object: never in the line
+
+
+def _pick(d, keys):
+    out = {}
+    for k in keys:
+        if d and k in d:
+            v = _scalar(d[k])
+            if v is not _scalar:
+                out[k] = v
+    return out
+
+
+def record_line(full, detail=DETAIL_NAME):
+    """the ONE line of stdout the driver keeps: the contract's top-level scalars + flat `config`, `roofline`, `cpu_baseline` (scalars only,
+    strings cut, no NaN / Infinity) + the name of the file with everything else.  Raises if the result would not fit the budget or lacks the
+    contract's fields -- a bench that cannot be recorded must fail loudly here, not in the driver's parser."""
+    line = _pick(full, TOP_KEYS)
+    missing = [k for k in TOP_KEYS if k not in line]
+    if missing:
+        raise ValueError(f"bench result lacks {missing}")
+    line["config"] = _pick(full.get("config"), CONFIG_KEYS)
+    line["roofline"] = _pick(full.get("roofline"), ROOF_KEYS) if full.get("roofline") else None
+    line["cpu_baseline"] = _pick(full.get("cpu_baseline"), CPU_KEYS) if full.get("cpu_baseline") else None
+    line.update(_pick(full, TOP_EXTRA))
+    if full.get("errors"):
+        line["errors"] = _scalar("; ".join(f"{k}: {v}" for k, v in full["errors"].items()), cut=300)
+    line["detail"] = detail
+    s = json.dumps(line, allow_nan=False)
+    if len(s) > LINE_BUDGET or "\n" in s:
+        raise ValueError(f"line of record is {len(s)} bytes (budget {LINE_BUDGET})")
+    return s
+
+
+def write_detail(full):
+    """everything the run measured, nested objects included: bench_detail.json beside bench.py and, where the directory exists or can be made
+    (a gpurun box merges it back), under gpurun_out/.  Never fails the bench."""
+    def clean(o):
+        if isinstance(o, dict):
+            return {str(k): clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        if isinstance(o, (float, np.floating)):
+            return float(o) if np.isfinite(o) else None
+        if isinstance(o, np.integer):
+            return int(o)
+        return o
+    body = json.dumps(clean(full), indent=1, allow_nan=False)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, DETAIL_NAME), "w") as f:
+                f.write(body + "\n")
+        except OSError as e:
+            print(f"bench.py: could not write {d}/{DETAIL_NAME}: {e}", file=sys.stderr)
+
+
 class Workload:
     """one BASELINE config on this rank's GPU: engine + network + the bookkeeping of the roofline"""
 
@@ -445,6 +537,7 @@ def run_single(name, game, G, sims, steps, warmup, waves):
     out = {"workload": w.desc, "concurrent_games": w.G, "games_per_step": G, "value": games / dt, "unit": "games/s", "examples_per_sec": n_samples / dt, "sims_per_sec": n_samples * sims / dt,
            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "plies_per_game": n_samples / games,
            "net_evals_per_step": evals / steps, "lockstep_iters_last_step": st["lockstep_iters"], "graph_replays": st["graph_replays"],
+           "us_per_lockstep": 1e6 * dt / steps / max(1, st["lockstep_iters"]),
            "max_tree_nodes_per_game": st["max_nodes_used"], "dtype": "f32"}
     out["roofline"] = w.profiled_wave((warmup + steps) * G, timed_evals=evals, timed_seconds=dt)
     w.close()
@@ -710,7 +803,7 @@ def run_dense_i8_prototype(sims, sizes=(4096, 32768)):
                 continue
             d = json.loads(lines[-1])
             out["sizes"][str(g)] = {"games_per_sec": d["value"], "us_per_lockstep": d["config"]["us_per_lockstep"], "examples_per_sec": d["examples_per_sec"],
-                                    "dense_layers": d["config"].get("dense_layers"), "full_batch_launch_ms": d["roofline"].get("full_batch_launch_ms")}
+                                    "dense_layers": d["config"].get("dense_layers")}
         except Exception as e:  # noqa: BLE001 -- an extra must never take the line of record down
             out["sizes"][str(g)] = {"error": repr(e)[:300]}
     return out
@@ -750,7 +843,7 @@ def main():
     ap.add_argument("--config5-eval-episodes", type=int, default=64)
     ap.add_argument("--config5-variants", default="", help="comma-separated subset of the config5 variants (default: all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-dense-i8", action="store_true", help="skip the AZ_DENSE_I8=1 prototype runs (child processes)")
+    ap.add_argument("--dense-i8", action="store_true", help="also run the opt-in AZ_DENSE_I8=1 prototype (child processes, after the line of record; detail file only)")
     ap.add_argument("--no-literal-configs", action="store_true", help="skip the saturated / config1 / config3 / config4 / config5 / latency objects")
     args = ap.parse_args()
 
@@ -847,29 +940,39 @@ def main():
         dist.barrier()
     t_lap = lap("headline_profiled_step", t_lap)
     saturated = config1 = config3 = config4 = config5 = latency = dense_i8 = None
+    errors = {}
+
+    def leg(name, fn):
+        """one optional leg.  On a single GPU a failing leg is recorded (`errors`) and never takes the line of record down; inside a
+        torch.distributed job it propagates: a rank that leaves a collective sequence would hang the others"""
+        nonlocal t_lap
+        try:
+            r = fn()
+        except Exception as e:  # noqa: BLE001
+            if world > 1:
+                raise
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            errors[name], r = repr(e)[:200], None
+        t_lap = lap(name, t_lap)
+        return r
+
+    only5 = [v for v in args.config5_variants.split(",") if v] or None
+    first5 = ["reference_batch_64_10_epochs"]  # the reference's own hyper-parameters: its scalars are in the line of record
     if not args.no_literal_configs:
         if args.saturated_games and args.saturated_games != args.games:
-            saturated = run_saturated(job, args.saturated_games, args.sims, steps=2, warmup=1, first_wave=1000)
-            t_lap = lap("saturated", t_lap)
+            saturated = leg("saturated", lambda: run_saturated(job, args.saturated_games, args.sims, steps=2, warmup=1, first_wave=1000))
         if world > 1 and args.config3_total // world != args.games:
-            config3 = run_config3(job, args.config3_total, args.sims, steps=2, warmup=1)
-            t_lap = lap("config3", t_lap)
+            config3 = leg("config3", lambda: run_config3(job, args.config3_total, args.sims, steps=2, warmup=1))
         if world == 1:
             # Othello games all last 60-65 plies: one synchronised wave per step keeps 92 % of the leaf rows filled (the rest are
             # terminal leaves, which need no evaluation).  Connect4 games last 18-42 plies: finished slots are refilled and a
             # step plays 8 x 8192 games, so that the drain at the end of a step (its length is one game) is amortised
-            config4 = run_single("config4", "connect4", args.config4_games, 200, steps=2, warmup=1, waves=8)
-            t_lap = lap("config4", t_lap)
-            config1 = run_config1()
-            t_lap = lap("config1", t_lap)
-        config5 = run_config5(job, args.config5_episodes, args.sims, eval_episodes=args.config5_eval_episodes, only=[v for v in args.config5_variants.split(",") if v] or None)
-        t_lap = lap("config5", t_lap)
-        if world == 1:
-            latency = run_latency(args.sims)
-            t_lap = lap("latency", t_lap)
-            if os.environ.get("AZ_DENSE_I8") != "1" and not args.no_dense_i8:
-                dense_i8 = run_dense_i8_prototype(args.sims, sizes=(args.games, args.saturated_games) if args.saturated_games else (args.games,))
-                t_lap = lap("dense_i8_prototype", t_lap)
+            config4 = leg("config4", lambda: run_single("config4", "connect4", args.config4_games, 200, steps=2, warmup=1, waves=8))
+            config1 = leg("config1", run_config1)
+        config5 = leg("config5", lambda: run_config5(job, args.config5_episodes, args.sims, eval_episodes=args.config5_eval_episodes,
+                                                      only=[v for v in first5 if only5 is None or v in only5] if world == 1 else only5))
+    full = None
     if rank == 0:
         cfg = out["config"]
         cfg["end_to_end_frac"] = roof.get("end_to_end_frac")
@@ -882,6 +985,7 @@ def main():
             c = compact(config4)
             cfg.update({"config4_games_per_sec": c["games_per_sec"], "config4_end_to_end_frac": c["end_to_end_frac"],
                         "config4_dominant_kernel": c["dominant_kernel"], "config4_dominant_frac": c["dominant_frac"],
+                        "config4_us_per_lockstep": config4.get("us_per_lockstep"),
                         "config4_workload": f"Connect4 6x7, {args.config4_games} concurrent games, 200 sims/move"})
         if config3 is not None:
             cfg.update({"config3_games_per_sec": config3["value"], "config3_concurrent_games_per_gpu": config3["concurrent_games_per_gpu"],
@@ -894,11 +998,6 @@ def main():
                 cfg.update({"config5_10_epochs_iteration_seconds": v10["iterations"][1]["iteration_seconds"],
                             "config5_10_epochs_sgd_share": v10["iterations"][1]["sgd_share"],
                             "config5_10_epochs_sgd_ms_per_step": v10["iterations"][1]["sgd_ms_per_step"]})
-        if dense_i8 is not None:
-            for g, key in ((args.games, "dense_i8_prototype_games_per_sec"), (args.saturated_games, "dense_i8_prototype_saturated_games_per_sec")):
-                v = dense_i8["sizes"].get(str(g), {})
-                if "games_per_sec" in v:
-                    cfg[key] = v["games_per_sec"]
         cfg["timed_region"] = "engine as shipped: HIP-graph replays, no event recording"
         cfg["dense_layers"] = ("exact block-fixed-point on the int8 matrix pipe (AZ_DENSE_I8=1: the roofline's f32 MFMA peak does not price fc1 / fc2)"
                                if os.environ.get("AZ_DENSE_I8") == "1" else "float32 fma chains on the f32-input MFMA")
@@ -908,21 +1007,52 @@ def main():
         if config4 is not None:
             roof["config4_frac"], roof["config4_end_to_end_frac"] = config4["roofline"]["frac"], config4["roofline"].get("end_to_end_frac")
             roof["config4_kernel"] = config4["roofline"]["kernel"][:40]
-        out["roofline"] = ordered(roof, ROOF_FIRST + ["saturated_frac", "saturated_end_to_end_frac", "config4_frac", "config4_end_to_end_frac"])
         sims_per_gpu = samples * args.sims / dt / world
         tree = {"algorithmic_bytes_per_sim": 919, "achieved": sims_per_gpu * 919 / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": sims_per_gpu * 919 / 8e12, "note": "per GPU, whole path: the tree kernels are a few % of a step, the path is bound by the network's MFMA work"}
         kfile, kwhy = stamped("kstep_counters.json")  # k_step<true,true>: duration + FETCH_SIZE / WRITE_SIZE passes (tools/refresh_profiles.sh)
         tree["k_step"] = kfile.get(kstep_key) if kfile else None
         tree["k_step_source"] = kwhy
+        if tree["k_step"]:  # flat copies for the line of record
+            ks = tree["k_step"]
+            roof["k_step_us"], roof["k_step_traffic_algorithmic"] = ks.get("duration_us_under_pmc"), ks.get("algorithmic_bytes_per_launch")
+            roof["k_step_traffic"] = ks.get("hbm_bytes_per_launch_lower")
+        out["roofline"] = ordered(roof, ROOF_FIRST + ["saturated_frac", "saturated_end_to_end_frac", "config4_frac", "config4_end_to_end_frac"])
         out["tree_hbm"] = tree
-        for name, obj in (("saturated", saturated), ("config1", config1), ("config3", config3), ("config4", config4), ("config5", config5),
-                          ("latency", latency), ("dense_i8_prototype", dense_i8), ("cpu_baseline", cpu)):
+        if cpu is not None:
+            cpu["reference_s_per_game"], cpu["reference_where"] = REF_S_PER_GAME_BUILD_CONTAINER, "Python reference, build container, 1 core (BASELINE.md 2)"
+        full = dict(out)
+        for name, obj in (("saturated", saturated), ("config1", config1), ("config3", config3), ("config4", config4), ("config5", config5), ("cpu_baseline", cpu)):
             if obj is not None:
-                out[name] = obj
-        phases["total"] = round(time.perf_counter() - t_start, 2)
-        out["bench_seconds"] = phases  # where the run's wall time went (the timed region is `ms_per_step` x `steps` of "headline_build_warmup_timed")
-        print(json.dumps(out), flush=True)
+                full[name] = obj
+        full["errors"] = errors
+        phases["until_line_of_record"] = round(time.perf_counter() - t_start, 2)
+        full["bench_seconds"] = phases  # where the run's wall time went (the timed region is `ms_per_step` x `steps` of "headline_build_warmup_timed")
+        write_detail(full)
+        # THE line of record: printed once, as soon as everything it carries is measured; nothing is written to stdout after it
+        print(record_line(full), flush=True)
+        sys.stdout.flush()
+        os.dup2(2, 1)  # whatever the remaining legs (or a library under them) print goes to stderr
+    # the remaining legs only feed bench_detail.json
+    if not args.no_literal_configs and world == 1:
+        rest5 = leg("config5_other_variants", lambda: run_config5(job, args.config5_episodes, args.sims, eval_episodes=args.config5_eval_episodes,
+                                                                   only=[v for v in ("reference_batch_64", "batch_512", "reference_batch_64_stock_pytorch")
+                                                                         if only5 is None or v in only5]))
+        if rest5 is not None and config5 is not None:
+            config5["variants"].update(rest5["variants"])
+            a, b = config5["variants"].get("reference_batch_64"), config5["variants"].get("reference_batch_64_stock_pytorch")
+            if a and b:
+                config5["sgd_ms_per_step_batch_64"] = {"hand_written": a["iterations"][1]["sgd_ms_per_step"], "stock_pytorch": b["iterations"][1]["sgd_ms_per_step"],
+                                                       "ratio": b["iterations"][1]["sgd_ms_per_step"] / a["iterations"][1]["sgd_ms_per_step"]}
+        latency = leg("latency", lambda: run_latency(args.sims))
+        if os.environ.get("AZ_DENSE_I8") != "1" and args.dense_i8:
+            dense_i8 = leg("dense_i8_prototype", lambda: run_dense_i8_prototype(args.sims, sizes=(args.games, args.saturated_games) if args.saturated_games else (args.games,)))
+        if rank == 0:
+            for name, obj in (("latency", latency), ("dense_i8_prototype", dense_i8)):
+                if obj is not None:
+                    full[name] = obj
+            phases["total"] = round(time.perf_counter() - t_start, 2)
+            write_detail(full)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

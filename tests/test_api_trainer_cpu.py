@@ -93,3 +93,31 @@ def test_optimize_network_matches_reference_losses(tag):
     # a wrong momentum / weight-decay constant must not pass: the fixture separates them
     if int(fx["epochs"]) > 1:
         assert np.abs(fx["pi_loss_0"] - fx["pi_loss_1"][: len(fx["pi_loss_0"])]).max() > 1e-3
+
+
+def test_print_config_and_freeze_config(tmp_path, capsys, monkeypatch):
+    """trainer.py:149-154, 580-587"""
+    import json
+    from alphazero_amd import base
+    from alphazero_amd.games.othello import OthelloConfig
+    from alphazero_amd.trainer import AlphaZeroTrainer, freeze_config
+    AlphaZeroTrainer.print_config(OthelloConfig())
+    out = capsys.readouterr().out
+    assert "- game: othello" in out and "- simulations: 100" in out and "- batch_size: 64" in out
+    AlphaZeroTrainer.print_config(OthelloConfig(), verbose=False)
+    assert capsys.readouterr().out == ""
+    monkeypatch.setattr(base, "DEFAULT_CONFIGS_PATH", str(tmp_path / "configs"))
+    freeze_config()
+    for game in ("othello", "connect4", "tictactoe"):
+        d = json.load(open(tmp_path / "configs" / f"{game}.json"))
+        assert d["game"] == game and d == dict(AlphaZeroTrainer.load_config_from_json(game, None).to_dict())
+
+
+def test_arena_play_game_binds_positionally_like_the_reference():
+    """arena.py:36-45: play_game(player2_starts, display, save_frames, return_results, ...): the fourth positional argument asks for results"""
+    board = BOARDS_REGISTER["tictactoe"]()
+    arena = Arena(RandomPlayer(), RandomPlayer(), board)
+    np.random.seed(1)
+    res = arena.play_game(False, False, False, True)
+    assert set(res) == {"winner", "score"} and res["winner"] in (0, 1, 2)
+    assert arena.play_game(True, False, False, False, True, False, False) is None

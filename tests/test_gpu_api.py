@@ -451,6 +451,23 @@ def test_timers_on_the_device():
     assert 0 < t_hip < 5e-3
 
 
+def test_estimate_training_duration_prints_the_references_lines(tmp_path, capsys):
+    """trainer.py:166-213 through the mirror: config from a JSON file, ten timed games, a hundred timed batches, five duration lines"""
+    import json
+    from alphazero_amd.games.tictactoe import TicTacToeConfig
+    from alphazero_amd.trainer import AlphaZeroTrainer
+    cfg = TicTacToeConfig(simulations=8, episodes=20, epochs=2, batch_size=16, iterations=3, device="cuda", do_eval=True, eval_episodes=4)
+    path = tmp_path / "ttt.json"
+    path.write_text(json.dumps(cfg.to_dict()))
+    AlphaZeroTrainer.estimate_training_duration("tictactoe", str(path))
+    out = capsys.readouterr().out
+    assert "- simulations: 8" in out and "- episodes: 20" in out  # print_config
+    for label in ("Self-play", "Optimization", "Iteration", "Evaluation", "TOTAL training"):
+        assert f"{label} duration: " in out and "(h:m:s)" in out
+    with pytest.raises(ValueError):
+        AlphaZeroTrainer.estimate_training_duration("othello", str(path))  # the game and the file's game do not match
+
+
 def test_randomised_augmentation_equals_host_mirror():
     """tools/fuzz_augment.py: 120 random sample sets (Othello 6 / 8, Connect4 5x5 .. 8x8, TicTacToe; 0 .. 400 samples; move indices on
     both sides of the move_idx >= 2 rule) -- the device twins equal the host mirror of the reference's augmentation in order, state,

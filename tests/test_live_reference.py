@@ -149,3 +149,98 @@ def test_checkpoints_cross_load(R, tmp_path):
     mine2 = OthelloNet.from_pretrained("m2", models_path=str(tmp_path))
     assert all(torch.equal(v, mine2.state_dict()[k]) for k, v in ref2.state_dict().items())
     assert mine2.n == 6 and sorted(OthelloConfig(board_size=6).to_dict()) == sorted(R.oth.OthelloConfig(board_size=6).to_dict())
+
+
+# ---------------------------------------------------------------------------------------------- the public surface
+# What the mirror deliberately does not carry, by name -- everything else public in the in-scope modules must exist here with the
+# reference's parameter names in the reference's order (extra trailing parameters need defaults):
+SURFACE_EXCEPTIONS = {
+    # rendering, the interactive player, HF hub and command lines: out of scope
+    "players.HumanPlayer", "utils.get_hf_token", "utils.list_models_from_hf_hub", "utils.download_model_from_hf_hub",
+    "utils.download_all_models_from_hf_hub", "utils.push_model_to_hf_hub", "utils.get_rgb_code", "timers.demo", "trainer.tests",
+    # the host-side tree of the reference: here the tree lives in HBM and these four steps are the device kernels k_step / k_rollout_step
+    # (csrc/az_engine.hip); MCT keeps search / get_action_probs / get_prior_probs / change_root / reset, which is what Players call
+    "mcts.Node", "mcts.MCT.select_node", "mcts.MCT.rollout", "mcts.MCT.nn_evaluation", "mcts.MCT.back_propagate",
+}
+SURFACE_MODULES = ["base", "arena", "mcts", "players", "trainer", "schedulers", "timers", "utils", "games.othello", "games.connect4",
+                   "games.tictactoe", "games.registers"]
+
+
+def _functions(cls):
+    import inspect
+    out = {}
+    for name, attr in vars(cls).items():
+        if name.startswith("_") and name != "__init__":  # private helpers (name-mangled or not) are not surface
+            continue
+        f = attr.__func__ if isinstance(attr, (staticmethod, classmethod)) else attr
+        if inspect.isfunction(f):
+            out[name] = (f, type(attr).__name__ if isinstance(attr, (staticmethod, classmethod)) else "function")
+    return out
+
+
+def test_public_surface_matches(R):
+    import importlib
+    import inspect
+    problems = []
+
+    def compare(label, rf, mf):
+        rp, mp = inspect.signature(rf).parameters, inspect.signature(mf).parameters
+        rn, mn = list(rp), list(mp)
+        if mn[:len(rn)] != rn:
+            problems.append(f"{label}: reference {rn}, mirror {mn}")
+            return
+        for extra in mn[len(rn):]:
+            if mp[extra].default is inspect.Parameter.empty and mp[extra].kind not in (inspect.Parameter.VAR_KEYWORD, inspect.Parameter.VAR_POSITIONAL):
+                problems.append(f"{label}: extra mirror parameter {extra} has no default")
+        for name in rn:
+            if (rp[name].default is inspect.Parameter.empty) != (mp[name].default is inspect.Parameter.empty) and name != "self":
+                problems.append(f"{label}: parameter {name} is {'required' if rp[name].default is inspect.Parameter.empty else 'optional'} in the reference")
+
+    for mod in SURFACE_MODULES:
+        ref, mine = importlib.import_module("alphazero." + mod), importlib.import_module("alphazero_amd." + mod)
+        for name, obj in vars(ref).items():
+            if getattr(obj, "__module__", None) != ref.__name__ or name.startswith("_") or name == "main":
+                continue
+            label = f"{mod}.{name}"
+            if label in SURFACE_EXCEPTIONS:
+                continue
+            if inspect.isfunction(obj):
+                if not hasattr(mine, name):
+                    problems.append(f"{label}: missing")
+                else:
+                    compare(label, obj, getattr(mine, name))
+            elif inspect.isclass(obj):
+                if not hasattr(mine, name):
+                    problems.append(f"{label}: missing")
+                    continue
+                theirs, ours = _functions(obj), getattr(mine, name)
+                for meth, (rf, kind) in theirs.items():
+                    ml = f"{label}.{meth}"
+                    if ml in SURFACE_EXCEPTIONS or meth in ("human_display", "pixel_display"):  # rendering: the base class refuses both
+                        continue
+                    attr = inspect.getattr_static(ours, meth, None)
+                    if attr is None:
+                        problems.append(f"{ml}: missing")
+                        continue
+                    mkind = type(attr).__name__ if isinstance(attr, (staticmethod, classmethod)) else "function"
+                    mf = attr.__func__ if isinstance(attr, (staticmethod, classmethod)) else attr
+                    if not inspect.isfunction(mf):
+                        problems.append(f"{ml}: not a function here")
+                    elif mkind != kind:
+                        problems.append(f"{ml}: {kind} in the reference, {mkind} here")
+                    else:
+                        compare(ml, rf, mf)
+    assert not problems, "\n".join(problems)
+
+
+def test_abstract_hooks_raise_like_the_reference(R):
+    """base.py:370-397: a hook a concrete network does not define is a NotImplementedError, not an AttributeError"""
+    from alphazero_amd.arena import Arena
+    from alphazero_amd.games.connect4 import Connect4Net
+    import inspect
+    with pytest.raises(NotImplementedError):
+        Connect4Net(7, 6).rotate_neural_output(np.zeros(7), 1)
+    with pytest.raises(NotImplementedError):
+        R.c4.Connect4Net(7, 6).rotate_neural_output(np.zeros(7), 1)
+    # a positional call binds as in the reference: play_game(False, False, False, True) asks for the results
+    assert list(inspect.signature(Arena.play_game).parameters)[:5] == ["self", "player2_starts", "display", "save_frames", "return_results"]
