@@ -2770,6 +2770,11 @@ extern "C" int az_net_create(int game, int H, int W, int max_batch, az_net **out
         if (frag_shape(n->F2, n->F1)) { NA(n->fc2wq, (size_t)n->F1 * n->F2) }
         NA(n->feat, (size_t)max_batch * n->FIN) NA(n->h1, (size_t)max_batch * n->F1) NA(n->h2, (size_t)max_batch * n->F2)
         n->qd_on = use_qdense(game) && n->FIN % 64 == 0 && n->F1 % 128 == 0 && n->F2 % 128 == 0 && n->F1 <= 1024 && n->FIN <= 1024;
+        if (rc == AZ_OK && use_qdense(game) && !n->qd_on) {
+            // the oracle switches every OthelloNet under the variable: a shape the fixed-point kernels do not tile must not silently run the f32 chains
+            az_set_error("AZ_DENSE_I8=1: no fixed-point dense kernels for FIN=%d, F1=%d, F2=%d (need FIN %% 64 = 0, F1 and F2 %% 128 = 0, both K <= 1024)", n->FIN, n->F1, n->F2);
+            rc = AZ_EINVAL;
+        }
         if (n->qd_on) {
             n->qd_rows = ((size_t)max_batch + 127) / 128 * 128;
             const size_t kmax = (size_t)(n->FIN > n->F1 ? n->FIN : n->F1);
@@ -3234,13 +3239,23 @@ static bool use_wino(int CH, int CW) {
 // (hipExtLaunchKernelGGL): they take the dispatch's own begin / end timestamps -- the two numbers rocprofv3 reports a kernel's duration
 // from -- so a slot's mean IS that kernel's average duration, with nothing to calibrate away (events recorded BETWEEN launches measure
 // marker to marker: kernel + 3-5 us of dispatch and marker processing).  Otherwise (and inside a graph capture) it is a plain launch.
-static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-static int g_ev_used = 0;
-#define AZ_LAUNCH(kern, grid, block, lds, st, ...)                                                                           \
+// The state is per host thread: az_net_profile brackets run_stage on the calling thread, and two networks forwarding from two threads
+// (an arena's two engines, a trainer beside a search) must not see each other's events or small-batch bookkeeping.
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static thread_local int g_ev_used = 0;
+#define AZ_LAUNCH_EV(ev0, ev1, kern, grid, block, lds, st, ...)                                                              \
     do {                                                                                                                     \
-        if (g_ev_start) { hipExtLaunchKernelGGL(kern, grid, block, lds, st, g_ev_start, g_ev_stop, 0, __VA_ARGS__); g_ev_used = 1; } \
+        if (g_ev_start) { hipExtLaunchKernelGGL(kern, grid, block, lds, st, ev0, ev1, 0, __VA_ARGS__); g_ev_used = 1; }      \
         else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                    \
     } while (0)
+#define AZ_LAUNCH(kern, grid, block, lds, st, ...) AZ_LAUNCH_EV(g_ev_start, g_ev_stop, kern, grid, block, lds, st, __VA_ARGS__)
+// a stage of TWO launches (k_q_rows + k_qgemm): the first carries the stage's start event, the second its stop event -- the slot then
+// holds first begin -> second end, the stage as the engine pays for it
+static thread_local int g_ev_split = 0;
+#define AZ_LAUNCH_FIRST(kern, grid, block, lds, st, ...)                                                                     \
+    do { AZ_LAUNCH_EV(g_ev_start, nullptr, kern, grid, block, lds, st, __VA_ARGS__); g_ev_split = 1; } while (0)
+#define AZ_LAUNCH_MAYBE_LAST(kern, grid, block, lds, st, ...)                                                                \
+    do { AZ_LAUNCH_EV(g_ev_split ? nullptr : g_ev_start, g_ev_stop, kern, grid, block, lds, st, __VA_ARGS__); g_ev_split = 0; } while (0)
 
 template <int CH, int CW, bool WINO>
 static int launch_trunk2(az_net *n, const float *in, int B, const int *dyn, hipStream_t st) {
@@ -3393,7 +3408,7 @@ static int frag_go(const float *A, const float *Bq, const float *bias, float *C,
     return AZ_OK;
 }
 
-static int g_last_gemm_small = 0;  // set by launch_gemm when it served the layer with a small-batch kernel (the profiler books those apart)
+static thread_local int g_last_gemm_small = 0;  // set by launch_gemm when it served the layer with a small-batch kernel (the profiler books those apart)
 
 static int launch_gemm(const float *A, const float *Bw, const float *Bq, const float *bias, float *C, int M, int N, int K, bool relu, const int *dyn, hipStream_t st) {
     AZ_REQUIRE(K % 32 == 0, AZ_EINVAL, "GEMM K=%d is not a multiple of 32", K);
@@ -3442,6 +3457,12 @@ static int launch_gemm(const float *A, const float *Bw, const float *Bq, const f
 }
 
 #define QD_SMALL_MAX 512  // rows up to which the one-launch small-batch kernel serves a fixed-point dense layer
+static int qd_small_max() {  // AZ_QD_SMALL_MAX overrides the row limit (0: never); launch_qdense and az_net_stage_kernel both ask here
+    static int v = -2;
+    if (v == -2) { const char *e = getenv("AZ_QD_SMALL_MAX"); v = e ? atoi(e) : QD_SMALL_MAX; }
+    return v;
+}
+static bool qd_small_serves(int B, int N, int K) { return B <= qd_small_max() && N % 64 == 0 && (K == 128 || K == 512 || K == 1024); }
 
 template <int NWM, int NWN, int WM, int WN>
 static int qgemm_go(az_net *n, int layer, int B, const int *dyn, hipStream_t st) {
@@ -3453,7 +3474,7 @@ static int qgemm_go(az_net *n, int layer, int B, const int *dyn, hipStream_t st)
         attr_set = true;
     }
     const int K = layer == 1 ? n->FIN : n->F1, N = layer == 1 ? n->F1 : n->F2;
-    AZ_LAUNCH((k_qgemm<NWM, NWN, WM, WN, true>), dim3((unsigned)(N / BN), (unsigned)((B + BM - 1) / BM)), dim3(64 * NWM * NWN), lds, st, n->qd_a,
+    AZ_LAUNCH_MAYBE_LAST((k_qgemm<NWM, NWN, WM, WN, true>), dim3((unsigned)(N / BN), (unsigned)((B + BM - 1) / BM)), dim3(64 * NWM * NWN), lds, st, n->qd_a,
               n->qd_rows * (size_t)K, n->qd_ea, layer == 1 ? n->qd_w1 : n->qd_w2, (size_t)N * K, layer == 1 ? n->qd_e1 : n->qd_e2, layer == 1 ? n->fc1b : n->fc2b,
               layer == 1 ? n->h1 : n->h2, B, N, K, dyn);
     return AZ_OK;
@@ -3462,9 +3483,7 @@ static int qgemm_go(az_net *n, int layer, int B, const int *dyn, hipStream_t st)
 // fc1 / fc2 in the exact block-fixed-point form: quantise the rows of the layer's input, then the int8 GEMM
 static int launch_qdense(az_net *n, int layer, int B, const int *dyn, hipStream_t st) {
     const int K = layer == 1 ? n->FIN : n->F1, N = layer == 1 ? n->F1 : n->F2;
-    static int small_max = -2;  // AZ_QD_SMALL_MAX: row limit of the one-launch small-batch kernel (0: never)
-    if (small_max == -2) { const char *e = getenv("AZ_QD_SMALL_MAX"); small_max = e ? atoi(e) : QD_SMALL_MAX; }
-    if (B <= small_max && N % 64 == 0 && (K == 128 || K == 512 || K == 1024)) {
+    if (qd_small_serves(B, N, K)) {
         const float *x = layer == 1 ? n->feat : n->h1;
         const int8_t *w = layer == 1 ? n->qd_w1 : n->qd_w2;
         const int *e = layer == 1 ? n->qd_e1 : n->qd_e2;
@@ -3477,7 +3496,7 @@ static int launch_qdense(az_net *n, int layer, int B, const int *dyn, hipStream_
         else AZ_LAUNCH((k_qdense_small<1024, true>), grid, dim3(256), 0, st, x, w, (size_t)N * K, e, bias, out, B, N, dyn);
         return AZ_OK;
     }
-    hipLaunchKernelGGL(k_q_rows, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, layer == 1 ? n->feat : n->h1, B, K, dyn, n->qd_a, n->qd_rows * (size_t)K, n->qd_ea);
+    AZ_LAUNCH_FIRST(k_q_rows, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, layer == 1 ? n->feat : n->h1, B, K, dyn, n->qd_a, n->qd_rows * (size_t)K, n->qd_ea);
     static int cfg = -1;  // AZ_QG_CFG: tile plan for A/B runs (every plan gives the same bits)
     if (cfg < 0) { const char *e = getenv("AZ_QG_CFG"); cfg = e ? atoi(e) : 0; }
     if (cfg == 1) return qgemm_go<2, 2, 1, 2>(n, layer, B, dyn, st);  // 64 x 128, four waves, two workgroups per CU
@@ -3761,7 +3780,7 @@ extern "C" int az_net_stage_kernel(const az_net *n, int stage, int B, char *buf,
         name = (tuned && !trunk_v1() && B >= 4096) ? (use_wino(n->CH, n->CW) ? "k_trunk2<Winograd conv2>" : "k_trunk2") : ((tuned && B <= trunk_q_max()) ? "k_trunk_q" : "k_trunk");
     }
     else if (stage == 3) name = (B <= heads_small_max(n) && n->NH <= 128 && n->F2 % 32 == 0) ? "k_heads_small" : (n->F2 == 512 ? "k_heads2" : "k_heads");
-    else if (n->qd_on) name = B <= QD_SMALL_MAX ? "k_qdense_small" : "k_qgemm";
+    else if (n->qd_on) name = qd_small_serves(B, stage == 1 ? n->F1 : n->F2, stage == 1 ? n->FIN : n->F1) ? "k_qdense_small" : "k_q_rows + k_qgemm";
     else {
         const int N = stage == 1 ? n->F1 : n->F2, K = stage == 1 ? n->FIN : n->F1;
         switch (gemm_kind(B, N, K, (stage == 1 ? n->fc1wq : n->fc2wq) != nullptr)) {

@@ -1584,7 +1584,11 @@ __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
     __shared__ double scr[768];
     if (blockIdx.x == 0) TBEG(16);
     if (blockIdx.x == gridDim.x - 1) TBEG(17);
-    const Hyper hp = *q.hp;
+    // The last workgroup advances step / perm_off / loss_off for the next step while the others are still running: nobody but that
+    // workgroup reads those three fields here; everybody reads lr / momentum / wd, which no kernel writes.
+    Hyper hp{};
+    hp.lr = q.hp->lr; hp.momentum = q.hp->momentum; hp.wd = q.hp->wd;
+    if (blockIdx.x == gridDim.x - 1) { hp.step = q.hp->step; hp.perm_off = q.hp->perm_off; hp.loss_off = q.hp->loss_off; }
     const int t = threadIdx.x;
     if (blockIdx.x >= gridDim.x - 4) {  // the last four workgroups: one BatchNorm2d layer's running statistics each (a walk over NB partials)
         const int l = (int)(gridDim.x - 1 - blockIdx.x);
@@ -2102,10 +2106,28 @@ extern "C" int az_trainer_store(az_trainer *t, const char *name, float *d_dst, i
     return relayout(t, name, d_dst, numel, 1, (hipStream_t)stream);
 }
 
+// The stream is idle: read and clear the sticky flag of sample_row.  `rejected` names the call that finds the flag of an EARLIER
+// az_trainer_steps call and therefore does nothing itself (nullptr: az_trainer_check, which reports on the steps it waited for).
+static int check_rows(az_trainer *t, const char *rejected = nullptr) {
+    int err = 0;
+    AZ_HIP(hipMemcpy(&err, &t->q.hp->err, sizeof err, hipMemcpyDeviceToHost));
+    if (err) {
+        const int zero = 0;
+        AZ_HIP(hipMemcpy(&t->q.hp->err, &zero, sizeof zero, hipMemcpyHostToDevice));
+        if (rejected)
+            AZ_REQUIRE(false, AZ_EINVAL, "%s rejected, nothing of it ran: a permutation entry of an EARLIER az_trainer_steps call was outside [0, n_samples) "
+                       "(those batch slots trained on row 0) and nobody had called az_trainer_check; the flag is now cleared", rejected);
+        AZ_REQUIRE(false, AZ_EINVAL, "a permutation entry of the last az_trainer_steps call was outside [0, n_samples): those batch slots trained on row 0");
+    }
+    return AZ_OK;
+}
+
 extern "C" int az_trainer_begin(az_trainer *t, float lr, float momentum, float weight_decay, float dropout_p, uint32_t seed, void *stream) {
     AZ_REQUIRE(t, AZ_EINVAL, "null argument");
     AZ_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, AZ_EINVAL, "dropout probability %g outside [0, 1)", (double)dropout_p);
     hipStream_t user = (hipStream_t)stream;
+    AZ_HIP(hipStreamSynchronize(t->stream));
+    AZ_TRY(check_rows(t, "az_trainer_begin"));  // h{} below would wipe an unreported flag: report it first, before anything is touched
     AZ_TRY(t_enter(t, user));
     for (auto &m : t->momenta) AZ_HIP(hipMemsetAsync(m.first, 0, m.second * sizeof(float), t->stream));
     Hyper h{};
@@ -2235,17 +2257,6 @@ static int enqueue_step(az_trainer *t) {  // (row tiles, waves that split K, pre
 
 // n_steps optimisation steps on device-resident samples: step s trains on rows d_perm[s * B .. s * B + B) of (d_state int8 [S][cells],
 // d_pi f32 [S][A], d_z int8 [S]) and writes its policy / value loss to d_loss_pi[s] / d_loss_v[s].  Asynchronous on `stream`.
-static int check_rows(az_trainer *t) {  // the stream is idle: read and clear the sticky flag of sample_row
-    int err = 0;
-    AZ_HIP(hipMemcpy(&err, &t->q.hp->err, sizeof err, hipMemcpyDeviceToHost));
-    if (err) {
-        const int zero = 0;
-        AZ_HIP(hipMemcpy(&t->q.hp->err, &zero, sizeof zero, hipMemcpyHostToDevice));
-        AZ_REQUIRE(false, AZ_EINVAL, "a permutation entry of the last az_trainer_steps call was outside [0, n_samples): those batch slots trained on row 0");
-    }
-    return AZ_OK;
-}
-
 // waits for the steps enqueued so far and reports a permutation entry that was out of range (the kernels clamp it and raise a flag)
 extern "C" int az_trainer_check(az_trainer *t) {
     AZ_REQUIRE(t, AZ_EINVAL, "null trainer");
@@ -2262,6 +2273,9 @@ extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const floa
     AZ_REQUIRE(n_steps >= 0, AZ_EINVAL, "negative step count");
     if (n_steps == 0) return AZ_OK;
     hipStream_t user = (hipStream_t)stream;
+    // the flag of an earlier call nobody checked: reported FIRST, while this call has changed nothing (cached graphs, pointers, Hyper)
+    AZ_HIP(hipStreamSynchronize(t->stream));
+    AZ_TRY(check_rows(t, "az_trainer_steps"));
     AZ_TRY(t_enter(t, user));
     const bool same = t->g_state == d_state && t->g_pi == d_pi && t->g_z == d_z && t->g_perm == d_perm && t->g_lp == d_loss_pi && t->g_lv == d_loss_v && t->g_B == B;
     if (!same && t->graph) { (void)hipGraphExecDestroy(t->graph); t->graph = nullptr; }
@@ -2278,8 +2292,7 @@ extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const floa
     t->q.state = d_state; t->q.pi = d_pi; t->q.z = d_z; t->q.perm = (const long long *)d_perm; t->q.loss_pi = d_loss_pi; t->q.loss_v = d_loss_v;
     t->tq.state = d_state; t->tq.pi = d_pi; t->tq.z = d_z; t->tq.perm = (const long long *)d_perm; t->tq.loss_pi = d_loss_pi; t->tq.loss_v = d_loss_v;
     t->g_state = d_state; t->g_pi = d_pi; t->g_z = d_z; t->g_perm = d_perm; t->g_lp = d_loss_pi; t->g_lv = d_loss_v; t->g_B = B;
-    AZ_HIP(hipStreamSynchronize(t->stream));
-    AZ_TRY(check_rows(t));  // of an earlier call nobody checked
+    AZ_HIP(hipStreamSynchronize(t->stream));  // t_enter ordered the stream behind the caller's: the Hyper tail below is written by the host
     // perm_off, loss_off: this call's arrays start at 0 (the step counter keeps running: dropout streams); n_samples bounds its rows
     struct { int perm_off, loss_off; long long n_samples; int err, pad_; } tail = {0, 0, (long long)n_samples, 0, 0};
     static_assert(sizeof tail == sizeof(Hyper) - offsetof(Hyper, perm_off), "Hyper tail layout");

@@ -289,8 +289,10 @@ class AlphaZeroTrainer:
                 and torch.device(self.config.device).type == "cuda" and train_step.supports(self.nn_twin, self.config.batch_size)):
             self.sgd_backend_used = "hip"
             return self._optimize_hip(iter_idx)
-        if self.sgd_backend == "hip" and self.device_memory is not None and torch.device(self.config.device).type == "cuda":
-            # never silent: the hand-written step was asked for and does not cover this network / batch size
+        if (self.sgd_backend == "hip" and self.device_memory is not None and torch.device(self.config.device).type == "cuda"
+                and not getattr(self, "_warned_sgd_fallback", False)):
+            # never silent, but once per trainer: "hip" is the default, a user who asked for nothing is not warned every iteration
+            self._warned_sgd_fallback = True
             import warnings
             warnings.warn(f"sgd_backend 'hip' does not cover {type(self.nn_twin).__name__} at batch size {self.config.batch_size} "
                           f"(csrc/az_train.hip: OthelloNet / Connect4Net at multiples of 16 up to 512, TicTacToeNet at 2..256): "

@@ -32,3 +32,11 @@ def golden(name):
 
 def unpack_mask(packed, A):
     return np.unpackbits(packed, axis=-1)[..., :A].astype(bool)
+
+
+def free_port():
+    """a TCP port free on 127.0.0.1 right now (rendezvous of a multi-process test: never a fixed number)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

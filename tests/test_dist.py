@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 
 def _worker(rank, world, port, ret):
@@ -51,7 +51,7 @@ def test_all_gather_samples_gloo_world2():
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, 29533, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, free_port(), ret), nprocs=world, join=True)
     assert all(ret[r][0] for r in range(world))
     ranges = [range(ret[r][1], ret[r][1] + ret[r][2]) for r in range(world)]
     assert not set(ranges[0]) & set(ranges[1])  # disjoint game ids -> disjoint Philox streams
@@ -81,7 +81,7 @@ def _worker_one(rank, world, port, ret):
 def test_forced_collectives_world1_gloo():
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_one, args=(1, 29534, ret), nprocs=1, join=True)
+    mp.spawn(_worker_one, args=(1, free_port(), ret), nprocs=1, join=True)
     assert ret[0]
 
 
@@ -104,7 +104,7 @@ def test_trainer_setup_hands_rank0_weights_to_every_rank():
     """without the broadcast in setup() wave 0 of a multi-GPU job plays with a different network per rank"""
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_worker_setup, args=(world, 29535, ret), nprocs=world, join=True)
+    mp.spawn(_worker_setup, args=(world, free_port(), ret), nprocs=world, join=True)
     assert all(torch.equal(ret[0][k], ret[1][k]) for k in ret[0])
     from alphazero_amd.games.othello import OthelloConfig
     from alphazero_amd.games.registers import NETWORKS_REGISTER
@@ -162,7 +162,7 @@ def test_world8_with_fewer_units_than_ranks():
     ranks with zero episodes / zero arena rounds / zero samples"""
     world = 8
     ret = mp.Manager().dict()
-    mp.spawn(_worker8, args=(world, 29541, ret), nprocs=world, join=True)
+    mp.spawn(_worker8, args=(world, free_port(), ret), nprocs=world, join=True)  # a free port: the test may run beside another copy of itself
     assert all(ret[r][0] for r in range(world)), {r: ret[r][0] for r in range(world)}
     ids = sorted(ret[r][1] for r in range(world))
     assert ids == [(2 * 8 + r) * 4096 for r in range(8)]  # config 3: 8 x 4096 disjoint game-id blocks per wave

@@ -402,7 +402,9 @@ def test_trainer_two_ranks_equal_one_rank(tmp_path):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
-    procs = [ctx.Process(target=_dist_trainer_worker, args=(r, 2, 29577, str(tmp_path), out)) for r in range(2)]
+    from conftest import free_port
+    port = free_port()
+    procs = [ctx.Process(target=_dist_trainer_worker, args=(r, 2, port, str(tmp_path), out)) for r in range(2)]
     [p.start() for p in procs]
     [p.join(300) for p in procs]
     assert all(p.exitcode == 0 for p in procs) and len(out) == 2

@@ -187,11 +187,20 @@ def test_backends_are_selectable_and_unsupported_shapes_use_the_stock_step():
             ts.check()
         ts.check()  # reported once, then clear
     ts.steps(m["state"], m["pi"], m["z"], bad, 1, 32, lp, lv)
-    with pytest.raises(ValueError, match="permutation entry"):  # nobody called check(): the next call reports it
-        ts.steps(m["state"], m["pi"], m["z"], good, 1, 32, lp, lv)
+    lp2, lv2 = torch.full((1,), -7.0, device="cuda"), torch.full((1,), -7.0, device="cuda")
+    with pytest.raises(ValueError, match="az_trainer_steps rejected, nothing of it ran.*permutation entry"):  # nobody called check(): the next call reports it
+        ts.steps(m["state"], m["pi"], m["z"], good, 1, 32, lp2, lv2)
+    torch.cuda.synchronize()
+    assert lp2.item() == -7.0 and lv2.item() == -7.0  # ... FIRST: the rejected call changed nothing
     ts.steps(m["state"], m["pi"], m["z"], good, 1, 32, lp, lv)
     ts.check()
     assert torch.isfinite(lp).all() and torch.isfinite(lv).all()
+    ts.steps(m["state"], m["pi"], m["z"], bad, 1, 32, lp, lv)
+    with pytest.raises(ValueError, match="az_trainer_begin rejected"):  # begin() would wipe the flag: it reports it instead
+        ts.begin(0.01, 0.9, 1e-4, 0.0, seed=1)
+    ts.begin(0.01, 0.9, 1e-4, 0.0, seed=1)
+    ts.steps(m["state"], m["pi"], m["z"], good, 1, 32, lp, lv)
+    ts.check()
     ts.close()
     # a module that is not the reference's architecture: not for the hand-written step
     from alphazero_amd.games.othello import OthelloNet
