@@ -122,7 +122,9 @@ def test_hand_written_step_matches_the_reference_fixture(tag):
     least twelve steps within 5e-5 of float64 (it pins the formula, the constants and the schedule over many steps); (b) after the
     first departure at most four times as far from float64 as the reference's own float32 run has been so far, or as an envelope
     growing 4x per step from 5e-5 (the hand-written step may take such a turn where the reference does not: 8x8, step 13); (c) beyond
-    epoch 0 the epoch mean within 25 % + 0.03 of the reference's."""
+    epoch 0, where both float32 runs have left float64 for good (the reference's by 1e-2 .. 3e-1 per step on 6x6), EVERY step at most
+    four times as far from the float64 trajectory as the reference's own float32 run has been up to that step (round 4 compared epoch
+    means within 25 % + 0.03; profiles/r05_g6_trajectories.txt holds the three trajectories)."""
     tr, fx = _fixture_trainer(tag, "hip")
     tr.optimize_network(0)
     assert tr.sgd_backend_used == "hip"
@@ -142,9 +144,13 @@ def test_hand_written_step_matches_the_reference_fixture(tag):
         ref_err = np.maximum.accumulate(np.abs(ref0 - np.array(f64[0][k])))  # how far the reference's own float32 run has strayed so far
         for i in range(clean, len(err)):
             assert err[i] <= 4 * max(ref_err[i], 5e-5 * 4.0 ** (i - clean + 1)), (tag, k, i, clean, err, ref_err)
+        far = float(ref_err[-1])  # the reference's own largest distance from float64 so far, carried over the epochs
         for e in range(1, int(fx["epochs"])):
-            got, ref = np.array(tr.loss_values[0][e][k]), fx[f"{k}_loss_{e}"]
-            assert got.shape == ref.shape and abs(got.mean() - ref.mean()) < 0.25 * ref.mean() + 0.03, (tag, e, k, got.mean(), ref.mean())
+            got, ref, exact = np.array(tr.loss_values[0][e][k]), fx[f"{k}_loss_{e}"], np.array(f64[e][k])
+            assert got.shape == ref.shape == exact.shape
+            for i in range(len(got)):  # every step of every later epoch: at most 4x as far from float64 as the reference's float32 run has been
+                far = max(far, abs(float(ref[i] - exact[i])))
+                assert abs(got[i] - exact[i]) <= 4 * far, (tag, e, k, i, abs(got[i] - exact[i]), far)
     sd = {k: v.cpu().numpy() for k, v in tr.nn_twin.state_dict().items()}
     if tag in ("connect4", "tictactoe"):
         assert np.abs(sd["fc1.weight"][:64] - fx["fc1_weight"]).max() < 1e-4
