@@ -1,14 +1,15 @@
 // az_train.hip -- the optimisation step of AlphaZeroTrainer.optimize_network (trainer.py:320-381) on MI355X (gfx950):
 // forward in TRAIN mode (BatchNorm batch statistics, dropout), loss, backward and the momentum-SGD update of OthelloNet /
-// Connect4Net (othello.py:341-382, connect4.py:370-412) as fifteen hand-written kernels per step, float32 in / float32
-// accumulate on the f32-input matrix cores (v_mfma_f32_16x16x4_f32), on device-resident samples.
+// Connect4Net (othello.py:341-382, connect4.py:370-412) as fourteen hand-written kernels per step (fifteen where several workgroups share
+// a board; nineteen above batch 128, where the dense layers are row-split), float32 in / float32 accumulate on the f32-input matrix cores
+// (v_mfma_f32_16x16x4_f32), on device-resident samples.
 //
 //   loss   = -sum(pi * log_softmax(logits)) / B + sum((tanh(u) - z)^2) / B                       (trainer.py:352-354)
 //   update = torch.optim.SGD(lr, momentum, weight_decay): g += wd p;  m = mu m + g;  p -= lr m  (trainer.py:326), on EVERY parameter
 //   BatchNorm (train): batch mean / biased variance, eps 1e-5; running stats <- 0.9 old + 0.1 (mean, unbiased variance)
 //   dropout p on the two dense layers: a Philox4x32-10 mask keyed (seed, step, layer, element) -- torch's own stream cannot be matched
 //
-// Why fifteen launches and no persistent kernel: train-mode BatchNorm puts a batch-wide reduction behind every layer, forward and
+// Why a chain of launches and no persistent kernel: train-mode BatchNorm puts a batch-wide reduction behind every layer, forward and
 // backward.  A dependent kernel boundary costs ~1.5 us on this chip, a grid-wide barrier inside one launch ~4-5 us
 // (MI355X_MICROARCH.md, rows "boundary" / "barrier-xcd"), so the reductions are cut at launch boundaries: every kernel leaves
 // per-workgroup partials (count / mean / M2 for the forward statistics, double sums for the backward ones), the consumer combines
@@ -26,9 +27,17 @@
 //   k_fc_dgrad        16 columns of fc1            d h1 (old W2), fc_bn1 backward
 //   k_mix1            tiles | 16 input columns     fc2 weight gradient + update | d a4 (old W1), ReLU mask, column sums for bn4
 //   k_mix2            tiles | boards               fc1 weight gradient + update | conv4 backward (data + weight partials)
-//   k_conv_bwd x2     boards                       conv3 / conv2 backward
-//   k_conv1_bwd       boards                       conv1 weight partials
+//   k_conv_bwd x2     boards                       conv3 / conv2 backward; conv2's also leaves conv1's weight gradient as per-board MOMENTS
+//                                                  (d.F1B: sum x_tap dy0, sum x_tap xhat0, sum x_tap -- the gradient is linear in them, with the
+//                                                  batch-wide BatchNorm sums as coefficients), which k_update combines
+//   k_conv1_bwd       boards                       conv1 weight partials -- only where d.F1B is off (workgroups sharing a board; batch > 128, where
+//                                                  its launch also carries fc1's weight-gradient tiles)
 //   k_update          elements                     conv weights / biases / BN2d affine: reduce partials + SGD; running stats; loss log; ++step
+// (rocprofv3 on a replayed step, profiles/r05_train_othello8_64_fold.txt: consecutive kernels follow each other with no gap; what a launch
+// costs is inside its own duration -- 5-6 us for k_update / k_conv1_fwd, which do next to nothing -- so a launch is worth removing only when
+// its work fits into a neighbour for less than that.  conv1's backward did (7.3 us gone, +0.8 per k_conv_bwd, +0.7 in k_update); conv1's
+// forward inside conv2's (statistics from the batch's 54 input moments, bit masks and popcounts: 25.6 against 5.8 + 12.6 us) and the two
+// heads kernels in one (every column workgroup recomputing the batch's logits: 52.8 against 13.4 + 11.3 us) did not and were taken out.)
 #include <math.h>
 #include <string.h>
 
@@ -98,7 +107,9 @@ struct TDims {
     int NRB;  // row blocks of the dense kernels: 1 = a workgroup sees ALL rows of its 16 columns (batch <= 128); above, the rows are split
               // into NRB blocks of RB so that the whole chip works, and the batch statistics go through per-block partials (k_fc_fin, k_bn1d_bwd_fin)
     int RB;   // rows per row block (multiple of 16)
+    int F1B;  // 1: conv1's weight gradient is folded into conv2's backward (per-board moment partials, combined by k_update): no k_conv1_bwd launch
 };
+#define C1P 640       // conv1 partial in the folded form: A[9][32] | C[9][32] | sum xhat [32] | Bx[9] (see conv_bwd_body, l = 1)
 #define NRBMAX 8
 
 struct TPtr {
@@ -1271,14 +1282,21 @@ __global__ __launch_bounds__(NW * 64) void k_mix1(TDims d, TPtr q, int nw) {
 //   weight gradient dW[tap][ic][oc] += sum_p a_{l-1}[p + tap - pad][ic] dz[p][oc]                (M = ic, N = oc, K = positions), one
 //                   (ic tile, oc tile) pair per wave, nine accumulators that live across the workgroup's boards
 // LDS: wl[288][LDP] | dzp[<=100][LDP] dz with a zero halo of 2 - pad | ap[<=100][LDP] a_{l-1} with a zero halo of pad | xh[64][LDP] | dpl[64][LDP]
-#define CONV_BWD_LDS_FLOATS (288 * LDP + 100 * LDP + 100 * LDP + 64 * LDP + 64 * LDP + 10 * 32 + 192)
+#define CONV_BWD_LDS_FLOATS (288 * LDP + 100 * LDP + 100 * LDP + 64 * LDP + 64 * LDP + 10 * 32 + 192 + 64 * LDP + 128 + 64)
 #define CONV_BWD_LDS_BYTES (CONV_BWD_LDS_FLOATS * 4 + 2048 * 8)
 AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblocks, float *lds) {
     float *wl = lds, *dzp = wl + 288 * LDP, *ap = dzp + 100 * LDP, *xh = ap + 100 * LDP, *dpl = xh + 64 * LDP;
     float *k1 = dpl + 64 * LDP, *sh_o = k1 + 32, *mean_o = sh_o + 32, *inv_o = mean_o + 32, *k2 = inv_o + 32, *k3 = k2 + 32;
     float *sc_i = k3 + 32, *sh_i = sc_i + 32, *mean_i = sh_i + 32, *inv_i = mean_i + 32;
-    double *scr = (double *)(inv_i + 32 + 192);
+    // l = 1 with d.F1B: the board's masked data gradient dy0 is kept as a plane (d0p) beside xhat0 (xh) and the board's input x (xin, haloed):
+    // conv1's weight gradient sum_p x[p + tap] dz0[p][oc] is LINEAR in three per-board moments -- A = sum x_tap dy0, C = sum x_tap xhat0,
+    // Bx = sum x_tap -- because dz0 = k1 (dy0 - k2 - k3 xhat0) with batch-wide k2, k3 that only the NEXT launch knows: the moments are
+    // formed here, k_update combines them (no k_conv1_bwd launch)
+    float *d0p = inv_i + 32 + 192, *xin = d0p + 64 * LDP;
+    int *p1off = (int *)(xin + 128);
+    double *scr = (double *)(p1off + 64);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n16 = lane & 15, kq = lane >> 4, ch = t & 31, grp = t >> 5;
+    const bool fold1 = l == 1 && d.F1B;
     const int Hin = conv_hin(d, l), Win = conv_win(d, l), Hout = conv_hout(d, l), Wout = conv_wout(d, l), pad = l == 1 ? 1 : 0, hal = 2 - pad;
     const int Pin = Hin * Win, Pout = Hout * Wout, WZ = Wout + 2 * hal, WA = Win + 2 * pad, MTin = (Pin + 15) / 16;
     const int GSZ = 9 * 32 * 32 + 32;
@@ -1287,7 +1305,7 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
     float *dyi = q.dy[l - 1];
     // a board's three planes travel through registers: the first board's loads go out before anything else, the next board's while
     // this one is being computed (<= 64 positions x 32 channels / 256 threads = 8 values per plane and thread)
-    float r_dy[8], r_co[8], r_ci[8];
+    float r_dy[8], r_co[8], r_ci[8], r_x = 0.0f;
     auto fetch = [&](int b) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -1295,6 +1313,7 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
             if (i < Pout * 32) { r_dy[k] = dyo[(size_t)b * Pout * 32 + i]; r_co[k] = co[(size_t)b * Pout * 32 + i]; }
             if (i < Pin * 32) r_ci[k] = ci[(size_t)b * Pin * 32 + i];
         }
+        if (fold1 && t < Pin) r_x = q.x0[(size_t)b * Pin + t];
     };
     const int S = d.S, part = bidx % S, bfirst = bidx / S, bstride = nblocks / S;
     if (bfirst < d.B) fetch(bfirst);
@@ -1318,6 +1337,10 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
     int *pzo = (int *)(inv_i + 32), *pao = pzo + 64, *pio = pao + 64;  // output position -> offset of its cell in dzp / of its top-left tap in ap; input position -> its cell in ap
     if (t < Pout) { pzo[t] = ((t / Wout + hal) * WZ + t % Wout + hal) * LDP; pao[t] = ((t / Wout) * WA + t % Wout) * LDP; }
     if (t < Pin) pio[t] = ((t / Win + pad) * WA + t % Win + pad) * LDP;
+    if (fold1) {
+        if (t < Pin) p1off[t] = (t / Win) * WA + t % Win;  // top-left tap of input position t in the haloed input plane
+        if (t < 128) xin[t] = 0.0f;
+    }
     __syncthreads();
     if (t < 32) {
         double S1 = 0.0, S2 = 0.0;
@@ -1334,7 +1357,9 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
     for (int i = 0; i < 9; ++i) wacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int wmt = wave >> 1, wnt = wave & 1;
     double s1 = 0.0, s2 = 0.0, sb = 0.0;  // this thread's share of sum dy, sum dy xhat (channel t & 31, rows t >> 5 and + 8 of every tile) and of sum dz
+    f32x4 facc = {0.f, 0.f, 0.f, 0.f}, fbx = {0.f, 0.f, 0.f, 0.f};  // fold1: this wave's 16 x 16 tile of the moment products (rows 4 kq + r = tap, columns 16 (wave & 1) + n16)
     for (int b = bfirst; b < d.B; b += bstride) {
+        if (fold1 && t < Pin) xin[(t / Win + 1) * WA + t % Win + 1] = r_x;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int i = t + TPB * k, p = i >> 5, cc = i & 31;
@@ -1377,6 +1402,7 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
                         const float v0 = ap[pio[mm] + n16] > 0.0f ? acc0[r] : 0.0f, v1 = ap[pio[mm] + 16 + n16] > 0.0f ? acc1[r] : 0.0f;
                         dyi[((size_t)b * Pin + mm) * 32 + n16] = v0; dyi[((size_t)b * Pin + mm) * 32 + 16 + n16] = v1;
                         dpl[mm * LDP + n16] = v0; dpl[mm * LDP + 16 + n16] = v1;
+                        if (fold1) { d0p[mm * LDP + n16] = v0; d0p[mm * LDP + 16 + n16] = v1; }
                     }
                 }
             }
@@ -1408,10 +1434,32 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
                     const float g = (dpl[rr * LDP + ch] + dpl[(16 + rr) * LDP + ch]) + (dpl[(32 + rr) * LDP + ch] + dpl[(48 + rr) * LDP + ch]);
                     const float v = ap[pio[mm] + ch] > 0.0f ? g : 0.0f;
                     dyi[((size_t)b * Pin + mm) * 32 + ch] = v;
+                    if (fold1) d0p[mm * LDP + ch] = v;
                     s1 += v; s2 += (double)v * (double)xh[mm * LDP + ch];
                 }
             }
             __syncthreads();
+        }
+        if (fold1) {  // (d0p is complete: both paths above end with a barrier)
+            // three small products on the matrix cores, K = the board's positions: rows = the nine shifted planes x_t (+ row 9 = ones, rows
+            // 10..15 = 0), columns = 32 channels of dy0 (waves 0, 1: A), of xhat0 (waves 2, 3: C; its row 9 is sum xhat), and, on wave 0, a
+            // column of ones (Bx[t] = sum x_t).  Accumulators live across the workgroup's boards.
+            const float *pln = (wave >> 1) ? xh : d0p;
+            const int toff = n16 < 9 ? (n16 / 3) * WA + n16 % 3 : 0, nt = wave & 1;
+            for (int p0 = 0; p0 < Pin; p0 += 16) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + 4 * u + kq, ok = p < Pin;
+                    av[u] = !ok ? 0.0f : (n16 < 9 ? xin[p1off[p] + toff] : (n16 == 9 ? 1.0f : 0.0f));
+                    bv[u] = ok ? pln[p * LDP + 16 * nt + n16] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    facc = MFMA(av[u], bv[u], facc);
+                    if (wave == 0) fbx = MFMA(av[u], 1.0f, fbx);
+                }
+            }
         }
         TSTAMP(3, 3);
         for (int p0 = 0; p0 < Pout; p0 += 8) {  // weight gradient of this workgroup's taps ((tap & (S - 1)) == part): K = output positions, four per MFMA,
@@ -1442,6 +1490,16 @@ AZ_D void conv_bwd_body(const TDims &d, const TPtr &q, int l, int bidx, int nblo
         if ((tap & (S - 1)) == part)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gp[(tap * 32 + 16 * wmt + 4 * kq + r) * 32 + 16 * wnt + n16] = wacc[tap][r];
+    if (fold1) {
+        float *g1p = q.gw[0] + (size_t)bidx * C1P;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tap = 4 * kq + r, oc = 16 * (wave & 1) + n16;
+            if (tap < 9) g1p[(wave >> 1) * 288 + tap * 32 + oc] = facc[r];
+            else if (tap == 9 && (wave >> 1)) g1p[576 + oc] = facc[r];   // sum xhat
+            if (wave == 0 && n16 == 0 && tap < 9) g1p[608 + tap] = fbx[r];
+        }
+    }
     scr[grp * 32 + ch] = s1; scr[256 + grp * 32 + ch] = s2; scr[512 + grp * 32 + ch] = sb;
     __syncthreads();
     if (t < 32) {
@@ -1581,17 +1639,19 @@ __global__ __launch_bounds__(TPB) void k_conv1_bwd(TDims d, TPtr q) {
 #define UPD_ALL (UPD_G + 4 * 32)
 __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
     __shared__ float s_mean[32], s_var[32];
-    __shared__ double scr[768];
+    __shared__ double scr[1280];
+    const int G = (int)gridDim.x - (d.F1B ? 6 : 0);  // the regular grid; behind it, with d.F1B, the six workgroups of conv1's folded gradient
+    const bool fold_wg = (int)blockIdx.x >= G;
     if (blockIdx.x == 0) TBEG(16);
-    if (blockIdx.x == gridDim.x - 1) TBEG(17);
+    if ((int)blockIdx.x == G - 1) TBEG(17);
     // The last workgroup advances step / perm_off / loss_off for the next step while the others are still running: nobody but that
     // workgroup reads those three fields here; everybody reads lr / momentum / wd, which no kernel writes.
     Hyper hp{};
     hp.lr = q.hp->lr; hp.momentum = q.hp->momentum; hp.wd = q.hp->wd;
-    if (blockIdx.x == gridDim.x - 1) { hp.step = q.hp->step; hp.perm_off = q.hp->perm_off; hp.loss_off = q.hp->loss_off; }
+    if ((int)blockIdx.x == G - 1) { hp.step = q.hp->step; hp.perm_off = q.hp->perm_off; hp.loss_off = q.hp->loss_off; }
     const int t = threadIdx.x;
-    if (blockIdx.x >= gridDim.x - 4) {  // the last four workgroups: one BatchNorm2d layer's running statistics each (a walk over NB partials)
-        const int l = (int)(gridDim.x - 1 - blockIdx.x);
+    if (!fold_wg && (int)blockIdx.x >= G - 4) {  // the last four regular workgroups: one BatchNorm2d layer's running statistics each
+        const int l = G - 1 - (int)blockIdx.x;
         if (t < 32) { s_mean[t] = q.fdone[l][t]; s_var[t] = q.fdone[l][128 + t]; }  // mean and biased variance as the forward pass finished them
         if (t < 32) {
             const double n = (double)d.B * plane_of(d, l);
@@ -1617,6 +1677,35 @@ __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
     double acc = 0.0;
     int kind = -1, l = 0, i = 0, c = 0;
     bool gam = false;
+    // d.F1B: conv1's gradient arrives as per-board moments (conv_bwd_body, l = 1) and is combined by SIX WORKGROUPS OF ITS OWN behind the
+    // regular grid (288 weights, 32 biases, BatchNorm 0's 64 affine values): every thread of them walks the same loads -- this wave's
+    // quarter of the NB partials of A, C, Bx (weights) or sum xhat (bias) and of BatchNorm 0's backward sums S1, S2 (nobody has finished
+    // bdone[0] in this form) -- sixteen partials per trip, every load before the first add.  The regular workgroups skip layer 0.
+    double f1[4] = {0.0, 0.0, 0.0, 0.0};
+    if (fold_wg) {
+        const int fe = ((int)blockIdx.x - G) * 64 + lane, oc = fe & 31;
+        const bool fw = fe < 288, fb = fe >= 288 && fe < 320;
+        const int ia = fw ? fe : 0, ic = fw ? 288 + fe : (fb ? 576 + oc : 0), ix = fw ? 608 + (fe >> 5) : 608;
+        const int per = (d.NB + 3) / 4, pbeg = part * per, pend = min(d.NB, pbeg + per);
+        for (int p0 = pbeg; p0 < pend; p0 += 16) {
+            double b1[16], b2[16];
+            float ga[16], gc[16], gx[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int p = p0 + u < pend ? p0 + u : pend - 1;
+                const float *g1p = q.gw[0] + (size_t)p * C1P;
+                b1[u] = q.bpart[0][(size_t)p * 64 + oc]; b2[u] = q.bpart[0][(size_t)p * 64 + 32 + oc];
+                ga[u] = g1p[ia]; gc[u] = g1p[ic]; gx[u] = g1p[ix];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (p0 + u < pend) { f1[0] += b1[u]; f1[1] += b2[u]; acc += ga[u]; f1[2] += gc[u]; f1[3] += gx[u]; }
+        }
+        kind = fw ? 3 : (fb ? 4 : 5);
+        l = 0; i = fe; c = oc; gam = fe >= 320 && fe < 352;
+    } else if (d.F1B && (e < UPD_W1 || (e >= UPD_W && e < UPD_W + 32) || (e >= UPD_B && e < UPD_ALL && ((e - UPD_B) & 127) < 32))) {
+        kind = -1;  // layer 0: the fold workgroups' (UPD_W, UPD_B, UPD_G are multiples of 32)
+    } else
     if (e < UPD_W) {
         kind = 0;
         l = e < UPD_W1 ? 0 : 1 + (e - UPD_W1) / 9216; i = e < UPD_W1 ? e : (e - UPD_W1) % 9216;
@@ -1652,8 +1741,30 @@ __global__ __launch_bounds__(TPB) void k_update(TDims d, TPtr q) {
         acc = S;
     }
     qs[part * 64 + lane] = acc;
+    if (kind >= 3) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) scr[256 * (k + 1) + part * 64 + lane] = f1[k];
+    }
     __syncthreads();
     if (part != 0 || kind < 0) return;
+    if (kind >= 3) {
+        double T[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) T[k] = ((scr[256 * k + lane] + scr[256 * k + 64 + lane]) + scr[256 * k + 128 + lane]) + scr[256 * k + 192 + lane];
+        const double S1 = T[1], S2 = T[2], Nn = (double)d.B * d.P1;
+        const float k1 = q.fdone[0][64 + c], k2 = (float)(S1 / Nn), k3 = (float)(S2 / Nn);  // as k_conv1_bwd forms them
+        if (kind == 3) {       // dW1[tap][oc] = k1 (A - k2 Bx - k3 C)
+            const float g = (float)((double)k1 * ((T[0] - (double)k2 * T[4]) - (double)k3 * T[3]));
+            sgd(q.p.cw[0] + i, q.m.cw[0] + i, g, hp);
+        } else if (kind == 4) {  // d b1[oc] = sum dz0 = k1 ((S1 - N k2) - k3 sum xhat): zero in exact arithmetic, the rounding of the two means in float32
+            const float g = (float)((double)k1 * ((S1 - Nn * (double)k2) - (double)k3 * T[3]));
+            sgd(q.p.cb[0] + c, q.m.cb[0] + c, g, hp);
+        } else {               // BatchNorm 0's affine pair: gamma <- sum dy xhat, beta <- sum dy
+            if (gam) sgd(q.p.bg[0] + c, q.m.bg[0] + c, (float)S2, hp);
+            else sgd(q.p.bb[0] + c, q.m.bb[0] + c, (float)S1, hp);
+        }
+        return;
+    }
     if (kind == 2) {
         const double S = ((qs[lane] + qs[64 + lane]) + qs[128 + lane]) + qs[192 + lane];
         if (gam) sgd(q.p.bg[l] + c, q.m.bg[l] + c, (float)S, hp);
@@ -2007,7 +2118,7 @@ extern "C" int az_trainer_create(int game, int H, int W, int max_batch, az_train
         TA(rm[l], 32); TA(rv[l], 32);
         const size_t P = l <= 1 ? d.P1 : (l == 2 ? d.P3 : d.P4);
         TA(c[l], B * P * 32); TA(dy[l], B * P * 32); TA(fpart[l], NBmax * FPART); TA(fdone[l], 160); TA(bdone[l], 64);
-        TA(gw[l], NBmax * (wn + 32));
+        TA(gw[l], NBmax * (l == 0 ? (size_t)C1P : wn + 32));
         if (l < 3) TA(bpart[l], NBmax * 64);
     }
     PA(w1, (size_t)d.F1 * d.FIN); PA(b1, d.F1); PA(g1, d.F1); PA(be1, d.F1);
@@ -2209,8 +2320,8 @@ static int enqueue_step_t(az_trainer *t) {
     hipLaunchKernelGGL(k_conv_bwd, dim3(d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, 2);
     hipLaunchKernelGGL(k_conv_bwd, dim3(d.NB), tb, CONV_BWD_LDS_BYTES, st, d, q, 1);
     if (wg_late) hipLaunchKernelGGL(k_conv1_bwd, dim3(d.NB + (d.F1 / 32) * (d.FIN / 32)), tb, CONV1_WG_LDS_BYTES, st, d, q);
-    else hipLaunchKernelGGL(k_conv1_bwd, dim3(d.NB), tb, 0, st, d, q);
-    hipLaunchKernelGGL(k_update, dim3((UPD_ALL + 63) / 64 + 4), tb, 0, st, d, q);
+    else if (!d.F1B) hipLaunchKernelGGL(k_conv1_bwd, dim3(d.NB), tb, 0, st, d, q);
+    hipLaunchKernelGGL(k_update, dim3((UPD_ALL + 63) / 64 + 4 + (d.F1B ? 6 : 0)), tb, 0, st, d, q);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
@@ -2288,6 +2399,11 @@ extern "C" int az_trainer_steps(az_trainer *t, const int8_t *d_state, const floa
         t->d.B = B; t->d.S = S; t->d.NB = B * S < 256 ? B * S : 256;
         const int rb = dense_row_block(B);
         t->d.RB = rb ? rb : B; t->d.NRB = rb ? (B + rb - 1) / rb : 1;
+        // conv1's backward folded into conv2's (one launch less) where a workgroup holds whole boards and fc1's weight gradient does not
+        // need k_conv1_bwd's launch (AZ_TRAIN_FOLD1=0: the separate kernel everywhere)
+        static int fold = -1;
+        if (fold < 0) { const char *e = getenv("AZ_TRAIN_FOLD1"); fold = e ? atoi(e) : 1; }
+        t->d.F1B = (fold && S == 1 && rb == 0) ? 1 : 0;
     }
     t->q.state = d_state; t->q.pi = d_pi; t->q.z = d_z; t->q.perm = (const long long *)d_perm; t->q.loss_pi = d_loss_pi; t->q.loss_v = d_loss_v;
     t->tq.state = d_state; t->tq.pi = d_pi; t->tq.z = d_z; t->tq.perm = (const long long *)d_perm; t->tq.loss_pi = d_loss_pi; t->tq.loss_v = d_loss_v;

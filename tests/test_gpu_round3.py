@@ -91,45 +91,52 @@ def _rehearse(n, *extra, timeout=1500, torchrun=False):
             port = sk.getsockname()[1]
         launcher += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port)]
     cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--sims", "8", *extra]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
-    return json.loads(lines[0])
+    import tempfile
+    with tempfile.TemporaryDirectory() as ddir:
+        env["AZ_BENCH_DETAIL_DIR"] = ddir
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        # THE line of record: the last line of stdout, one JSON object of scalars, far below the driver's 8 KB
+        assert lines and lines[-1].startswith("{") and len([ln for ln in lines if ln.startswith("{")]) == 1, p.stdout[-2000:]
+        assert len(lines[-1]) < 8192
+        line = json.loads(lines[-1], parse_constant=lambda c: (_ for _ in ()).throw(AssertionError(c)))
+        for k in ("config", "roofline"):
+            assert all(v is None or isinstance(v, (bool, int, float, str)) for v in line[k].values()), k
+        assert all(not isinstance(v, (dict, list)) for k, v in line.items() if k not in ("config", "roofline", "cpu_baseline"))
+        detail = json.load(open(os.path.join(ddir, line["detail"])))
+    return line, detail
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
     """two self-launched ranks: the line must say n_gpus 2, carry per-rank times, the flat summaries inside `config` / `roofline` (what
     the driver's record keeps) and the saturated / config3 / config5 objects"""
-    out = _rehearse(2, "--games", "64", "--saturated-games", "96", "--config3-total", "64", "--config5-episodes", "64")
-    assert out["n_gpus"] == 2 and out["unit"] == "games/s" and out["value"] > 0
+    line, out = _rehearse(2, "--games", "64", "--saturated-games", "96", "--config3-total", "64", "--config5-episodes", "64")
+    assert line["n_gpus"] == 2 and line["unit"] == "games/s" and line["value"] > 0 and out["n_gpus"] == 2
     assert len(out["per_rank_ms_per_step"]) == 2 and len(out["per_rank_gather_ms_per_step"]) == 2
-    assert out["config"]["concurrent_games_per_gpu"] == 64 and out["config"]["end_to_end_frac"] > 0
+    assert line["config"]["concurrent_games_per_gpu"] == 64 and line["config"]["end_to_end_frac"] > 0
     assert out["config3"]["n_gpus"] == 2 and out["config3"]["concurrent_games_per_gpu"] == 32 and out["config3"]["value"] > 0
-    assert out["config"]["config3_games_per_sec"] == out["config3"]["value"]
-    assert out["saturated"]["concurrent_games"] == 96 and out["config"]["saturated_games_per_sec"] == out["saturated"]["value"] > 0
-    assert out["roofline"]["saturated_frac"] == out["saturated"]["roofline"]["frac"] <= 1.0
+    close = lambda a, b: abs(a - b) <= 1e-5 * abs(b)  # the line rounds to six significant digits
+    assert close(line["config"]["config3_games_per_sec"], out["config3"]["value"])
+    assert out["saturated"]["concurrent_games"] == 96 and close(line["config"]["saturated_games_per_sec"], out["saturated"]["value"]) and out["saturated"]["value"] > 0
+    assert close(line["roofline"]["saturated_frac"], out["saturated"]["roofline"]["frac"]) and out["saturated"]["roofline"]["frac"] <= 1.0
     v = out["config5"]["variants"]
     assert set(v) == {"reference_batch_64", "reference_batch_64_10_epochs", "batch_512", "reference_batch_64_stock_pytorch"}
     assert all(len(x["iterations"]) == 2 for x in v.values())
     assert v["reference_batch_64"]["sgd_step"].startswith("hand-written") and v["reference_batch_64_stock_pytorch"]["sgd_step"] == "stock PyTorch"
     assert all(it["seconds"]["optimize_network"] > 0 and it["eval_results"] for x in v.values() for it in x["iterations"])
     assert v["reference_batch_64_10_epochs"]["iterations"][1]["sgd_steps"] == 10 * (v["reference_batch_64_10_epochs"]["iterations"][1]["samples_with_twins"] // 64)
-    assert out["config"]["config5_10_epochs_sgd_share"] == v["reference_batch_64_10_epochs"]["iterations"][1]["sgd_share"]
-    assert out["roofline"]["frac"] <= 1.0 and "end_to_end_frac" in out["roofline"]
-    # the scalars the driver's record keeps come before any nested object
-    for d in (out["config"], out["roofline"]):
-        kinds = [isinstance(x, (dict, list)) for x in d.values()]
-        assert kinds == sorted(kinds)
+    assert close(line["config"]["config5_10_epochs_sgd_share"], v["reference_batch_64_10_epochs"]["iterations"][1]["sgd_share"])
+    assert line["roofline"]["frac"] <= 1.0 and "end_to_end_frac" in line["roofline"] and not out["errors"]
 
 
 def test_bench_as_one_rank_under_torch_distributed_run():
     """the driver's launch line for N > 1, two ranks in rehearsal mode: headline + saturated + config5 (one variant) come out as under
     the self-launch"""
-    out = _rehearse(2, "--games", "32", "--saturated-games", "48", "--config3-total", "64", "--config5-episodes", "64",
-                    "--config5-variants", "reference_batch_64", "--config5-eval-episodes", "4", torchrun=True)
-    assert out["n_gpus"] == 2 and len(out["per_rank_ms_per_step"]) == 2 and out["value"] > 0
-    assert out["config"]["concurrent_games_per_gpu"] == 32 and out["saturated"]["concurrent_games"] == 48
+    line, out = _rehearse(2, "--games", "32", "--saturated-games", "48", "--config3-total", "64", "--config5-episodes", "64",
+                          "--config5-variants", "reference_batch_64", "--config5-eval-episodes", "4", torchrun=True)
+    assert line["n_gpus"] == 2 and len(out["per_rank_ms_per_step"]) == 2 and line["value"] > 0
+    assert line["config"]["concurrent_games_per_gpu"] == 32 and out["saturated"]["concurrent_games"] == 48
     assert "config3" not in out  # 64 / 2 = the headline's 32 per GPU: config 3 IS the headline
     assert len(out["config5"]["variants"]["reference_batch_64"]["iterations"]) == 2
 
@@ -140,10 +147,10 @@ def test_bench_rehearsal_with_five_ranks_and_an_idle_rank():
     pool admits at most six processes on its card and this test process is one of them, so eight ranks cannot be started here (the
     world-8 arithmetic and collectives run on the CPU in tests/test_dist.py::test_world8_with_fewer_units_than_ranks).  config 5 runs
     with 4 evaluation games -> the fifth rank plays no arena round; its results must equal a single process's."""
-    out = _rehearse(5, "--games", "32", "--saturated-games", "0", "--config3-total", "80", "--config5-episodes", "64",
-                    "--config5-variants", "reference_batch_64", "--config5-eval-episodes", "4")
-    assert out["n_gpus"] == 5 and len(out["per_rank_ms_per_step"]) == 5 and all(t > 0 for t in out["per_rank_ms_per_step"])
-    assert out["config"]["concurrent_games_per_gpu"] == 32 and abs(out["plies_per_game"] - 60.5) < 3
+    line, out = _rehearse(5, "--games", "32", "--saturated-games", "0", "--config3-total", "80", "--config5-episodes", "64",
+                          "--config5-variants", "reference_batch_64", "--config5-eval-episodes", "4")
+    assert line["n_gpus"] == 5 and len(out["per_rank_ms_per_step"]) == 5 and all(t > 0 for t in out["per_rank_ms_per_step"])
+    assert line["config"]["concurrent_games_per_gpu"] == 32 and abs(line["plies_per_game"] - 60.5) < 3
     assert out["config3"]["concurrent_games_per_gpu"] == 16 and out["config3"]["n_gpus"] == 5
     multi = out["config5"]["variants"]["reference_batch_64"]["iterations"]
     import bench

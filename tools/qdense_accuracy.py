@@ -4,7 +4,8 @@ carry a headline: >= 1e5 positions drawn from REAL self-play, random-init (seed 
 yardstick (not the oracle, which restates whichever arithmetic the switch selects).
 
     python tools/qdense_accuracy.py make FILE     self-play (engine, random-init OthelloNet seed 0) -> boards; a few hundred SGD steps on
-                                                  those samples (hand-written step) -> post-SGD weights; both saved to FILE (npz)
+                                                  those samples (hand-written step) -> post-SGD weights; torch float64 outputs; all saved to
+                                                  FILE (npz); then `eval` of this process's own arithmetic
     python tools/qdense_accuracy.py eval FILE     this process's arithmetic (AZ_DENSE_I8 unset: float32 fma chains on the f32 MFMA;
                                                   AZ_DENSE_I8=1: fc1 / fc2 as exact block-fixed-point int8 GEMMs) against torch float64 on
                                                   FILE's boards and both weight sets -> one JSON line
@@ -20,6 +21,8 @@ import torch
 from alphazero_amd import engine as E
 from alphazero_amd.games.othello import OthelloNet
 from alphazero_amd.train_step import HipTrainStep
+
+CHUNK = 16384
 
 
 def make(path, games=2048, sims=16, sgd_steps=400, batch=64):
@@ -47,15 +50,31 @@ def make(path, games=2048, sims=16, sgd_steps=400, batch=64):
     step.store(train)
     step.close()
     out = {"boards": state.view(S, 64).cpu().numpy(), "loss_pi_first_last": np.array([lp[0].item(), lp[-1].item()])}
+    # the yardstick, once: torch float64 on the GPU (and stock torch float32 beside it, for scale) -- every `eval` process reads them from the file
+    boards = state.view(S, 64).float()
+    pad = (-S) % CHUNK  # one batch shape for MIOpen (its algorithm search runs per shape and per dtype)
+    padded = torch.cat([boards, boards[:pad]]) if pad else boards
     for tag, m in (("init", net), ("sgd", train)):
         for k, v in m.state_dict().items():
             if v.dtype == torch.float32:
                 out[f"{tag}/{k}"] = v.detach().cpu().numpy()
-    np.savez_compressed(path, **out)
+        ref, f32 = m.clone().double().cuda().eval(), m.clone().float().cuda().eval()
+        p64, v64, p32, v32 = [], [], [], []
+        with torch.no_grad():
+            for i in range(0, padded.shape[0], CHUNK):
+                x = padded[i:i + CHUNK].view(-1, 8, 8)
+                a, b = ref(x.double()); p64.append(torch.exp(a)); v64.append(b.view(-1))
+                a, b = f32(x); p32.append(torch.exp(a)); v32.append(b.view(-1))
+        p64, v64, p32, v32 = torch.cat(p64)[:S], torch.cat(v64)[:S], torch.cat(p32)[:S], torch.cat(v32)[:S]
+        out[f"{tag}.p64"], out[f"{tag}.v64"] = p64.cpu().numpy(), v64.cpu().numpy()
+        dp, dv = (p32.double() - p64).abs(), (v32.double() - v64).abs()
+        out[f"{tag}.torch_f32"] = np.array([dp.max().item(), dp.mean().item(), dv.max().item(), dv.mean().item()])
+    np.savez(path, **out)
     print(f"{S} self-play positions ({games} games at {sims} sims), {sgd_steps} SGD steps at batch {batch}: policy loss {lp[0].item():.3f} -> {lp[-1].item():.3f}; saved {path}")
+    evaluate(path)  # this process's own arithmetic right away: one process start less for the caller
 
 
-def evaluate(path, chunk=16384):
+def evaluate(path):
     d = np.load(path)
     boards = torch.tensor(d["boards"].astype(np.float32), device="cuda")
     S = boards.shape[0]
@@ -66,24 +85,17 @@ def evaluate(path, chunk=16384):
         net = OthelloNet(n=8)
         net.load_state_dict(sd, strict=False)
         net.eval()
-        hnet = net.to_hip(max_batch=chunk)
-        ref = net.clone().double().cuda().eval()
-        ref.device = torch.device("cuda")
-        f32 = net.clone().cuda().eval()
-        dp, dv, tp, tv = [], [], [], []
-        with torch.no_grad():
-            for i in range(0, S, chunk):
-                x = boards[i:i + chunk]
-                p, v = hnet.forward(x)
-                lp64, v64 = ref(x.view(-1, 8, 8).double())
-                p64, v64 = torch.exp(lp64), v64.view(-1)
-                dp.append((p.double() - p64).abs()); dv.append((v.double() - v64).abs())
-                lp32, v32 = f32(x.view(-1, 8, 8))  # stock PyTorch float32 (rocBLAS / MIOpen) on the same boards, for scale
-                tp.append((torch.exp(lp32).double() - p64).abs()); tv.append((v32.view(-1).double() - v64).abs())
-        dp, dv, tp, tv = torch.cat(dp), torch.cat(dv), torch.cat(tp), torch.cat(tv)
+        hnet = net.to_hip(max_batch=CHUNK)
+        p64, v64 = torch.tensor(d[f"{tag}.p64"], device="cuda"), torch.tensor(d[f"{tag}.v64"], device="cuda")
+        dp, dv = [], []
+        for i in range(0, S, CHUNK):
+            p, v = hnet.forward(boards[i:i + CHUNK])
+            dp.append((p.double() - p64[i:i + CHUNK]).abs()); dv.append((v.double() - v64[i:i + CHUNK]).abs())
+        dp, dv = torch.cat(dp), torch.cat(dv)
+        t32 = d[f"{tag}.torch_f32"]
         res[tag] = {"pi_max": dp.max().item(), "pi_mean": dp.mean().item(), "v_max": dv.max().item(), "v_mean": dv.mean().item(),
-                    "torch_f32_pi_max": tp.max().item(), "torch_f32_pi_mean": tp.mean().item(), "torch_f32_v_max": tv.max().item(), "torch_f32_v_mean": tv.mean().item(),
-                    "dense_kernels": f"{hnet.stage_kernel(1, chunk)} / {hnet.stage_kernel(2, chunk)}"}
+                    "torch_f32_pi_max": float(t32[0]), "torch_f32_pi_mean": float(t32[1]), "torch_f32_v_max": float(t32[2]), "torch_f32_v_mean": float(t32[3]),
+                    "dense_kernels": f"{hnet.stage_kernel(1, CHUNK)} / {hnet.stage_kernel(2, CHUNK)}"}
         hnet.close()
     print(json.dumps(res))
 
