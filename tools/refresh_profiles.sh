@@ -38,7 +38,8 @@ cp $OUT/${TAG}_mfma_counters.json profiles/mfma_counters.json 2>/dev/null
 cp $OUT/${TAG}_kstep_counters.json profiles/kstep_counters.json 2>/dev/null
 if [ $ONLY = all ] || [ $ONLY = bench ]; then
 python3 bench.py > $OUT/${TAG}_bench.log 2>&1
-grep '^{' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench.json
+grep '^{' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench.json   # the line of record (scalars only)
+cp $R/bench_detail.json $OUT/${TAG}_bench_detail.json                   # every nested object of the same run
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o k -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-literal-configs > $OUT/${TAG}_prof.log 2>&1
 # the literal BASELINE configs, one process each, so that their kernels do not mix in one table
