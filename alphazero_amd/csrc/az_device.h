@@ -255,10 +255,11 @@ AZ_D u64 az_legal_bits(const GameDesc& gd, const BB& b, int player) {
 }
 
 AZ_D int az_bit_to_action(const GameDesc& gd, int bit) {
-    return gd.game == AZ_CONNECT4 ? bit : (bit >> 3) * gd.W + (bit & 7);
+    return (gd.game == AZ_CONNECT4 || gd.W == 8) ? bit : (bit >> 3) * gd.W + (bit & 7);
 }
 AZ_D int az_action_to_bit(const GameDesc& gd, int a) {
-    return gd.game == AZ_CONNECT4 ? a : (a / gd.W) * 8 + (a % gd.W);
+    // (an 8-wide board: cell index = bit index, and no integer division on the tree walk's path)
+    return (gd.game == AZ_CONNECT4 || gd.W == 8) ? a : (a / gd.W) * 8 + (a % gd.W);
 }
 
 // plays a LEGAL action (legality is the caller's business); flips the side to move
@@ -323,10 +324,23 @@ AZ_D DirLane az_dir_lane(int sub) {
     return L;
 }
 AZ_D u64 dsh(const DirLane& L, u64 x) { return (L.left ? (x << L.amt) : (x >> L.amt)) & L.mask; }
+// Group reductions by DPP: lane permutations inside the VALU (a few cycles each) instead of ds_bpermute shuffles through the LDS crossbar
+// (~100 cycles each, three to four dependent ones per reduction, several reductions per tree level on a SIMD that holds one wave).  A game's
+// 16 lanes are one DPP row.  quad_perm swaps neighbours / pairs, row_half_mirror maps lane i of an 8-lane half to 7 - i, row_mirror lane i
+// of the row to 15 - i: for a commutative, idempotent combine (OR, max) three steps cover 8 lanes, four cover 16, and every lane ends with
+// the full result -- the same value the butterfly of shuffles gave.
+#define AZ_DPP_SWAP1 0xB1     // quad_perm [1, 0, 3, 2]
+#define AZ_DPP_SWAP2 0x4E     // quad_perm [2, 3, 0, 1]
+#define AZ_DPP_HMIRROR 0x141  // row_half_mirror
+#define AZ_DPP_MIRROR 0x140   // row_mirror
+template <int CTRL>
+AZ_D u32 az_dpp(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+AZ_D u64 az_dpp64(u64 v) { return ((u64)az_dpp<CTRL>((u32)(v >> 32)) << 32) | (u64)az_dpp<CTRL>((u32)v); }
 AZ_D u64 or8(u64 v) {
-    v |= (u64)__shfl_xor((long long)v, 1, 8);
-    v |= (u64)__shfl_xor((long long)v, 2, 8);
-    v |= (u64)__shfl_xor((long long)v, 4, 8);
+    v |= az_dpp64<AZ_DPP_SWAP1>(v);
+    v |= az_dpp64<AZ_DPP_SWAP2>(v);
+    v |= az_dpp64<AZ_DPP_HMIRROR>(v);
     return v;
 }
 AZ_D u64 oth_legal_dir(const DirLane& L, u64 own, u64 opp, u64 empty) {
@@ -361,7 +375,7 @@ AZ_D bool az_status_grp(const GameDesc& gd, const BB& b, int* winner, int sub) {
     const bool second = (sub & 8) != 0;
     const u64 own = second ? b.m1 : b.p1, opp = second ? b.p1 : b.m1;
     u64 any = or8(oth_legal_dir(az_dir_lane(sub), own, opp, ~(own | opp) & gd.valid));
-    any |= (u64)__shfl_xor((long long)any, 8, 16);
+    any |= az_dpp64<AZ_DPP_MIRROR>(any);  // the other colour's half of the row
     if (any) return false;
     int d = __popcll(b.p1) - __popcll(b.m1);
     *winner = d > 0 ? 1 : (d < 0 ? -1 : 0);

@@ -124,9 +124,11 @@ AZ_D Node *pool_of(const EngDev &E, int g) { return E.nodes + ((size_t)g * 2 + E
 AZ_D bool searches(const EngDev &E, int g) { return E.active[g] && (E.side[g] == 0 || E.side[g] == E.root_player[g]); }
 
 AZ_D u32 grp_ballot(bool p) { return (u32)(__ballot(p) >> (threadIdx.x & 48)) & 0xFFFFu; }
-AZ_D double grp_max(double v) {
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, LPG));
+AZ_D double grp_max(double v) {  // over the game's 16 lanes, by DPP (az_device.h: the same maximum in every lane as the shuffle butterfly gave)
+    v = fmax(v, __longlong_as_double((long long)az_dpp64<AZ_DPP_SWAP1>((u64)__double_as_longlong(v))));
+    v = fmax(v, __longlong_as_double((long long)az_dpp64<AZ_DPP_SWAP2>((u64)__double_as_longlong(v))));
+    v = fmax(v, __longlong_as_double((long long)az_dpp64<AZ_DPP_HMIRROR>((u64)__double_as_longlong(v))));
+    v = fmax(v, __longlong_as_double((long long)az_dpp64<AZ_DPP_MIRROR>((u64)__double_as_longlong(v))));
     return v;
 }
 AZ_D u64 grp_sum_u64(u64 v) {
