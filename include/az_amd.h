@@ -225,7 +225,8 @@ int az_trainer_set_lr(az_trainer *t, float lr, void *stream); /* ExponentialLR b
  * d_pi float [S][A], d_z int8 [S], S = n_samples = len(memory) of trainer.py:288-318, whose indices d_perm holds) and writes its
  * losses to d_loss_pi[s], d_loss_v[s] (trainer.py:352-353).  Asynchronous.  A permutation entry outside [0, n_samples) is never
  * used as an address: the kernels train that batch slot on row 0 and raise a sticky flag, reported as AZ_EINVAL by az_trainer_check
- * (which waits for the enqueued steps) or by the next az_trainer_steps call. */
+ * (which waits for the enqueued steps) or by the next az_trainer_steps / az_trainer_begin call -- which checks the flag FIRST and, when
+ * it reports it, has changed nothing and enqueued nothing of its own (the flag is cleared by the report: repeat the call). */
 int az_trainer_steps(az_trainer *t, const int8_t *d_state, const float *d_pi, const int8_t *d_z, int64_t n_samples, const int64_t *d_perm,
                      int32_t n_steps, int32_t B, float *d_loss_pi, float *d_loss_v, void *stream);
 int az_trainer_check(az_trainer *t);
