@@ -195,6 +195,10 @@ def test_public_surface_matches(R):
         for name in rn:
             if (rp[name].default is inspect.Parameter.empty) != (mp[name].default is inspect.Parameter.empty) and name != "self":
                 problems.append(f"{label}: parameter {name} is {'required' if rp[name].default is inspect.Parameter.empty else 'optional'} in the reference")
+            elif rp[name].default is not inspect.Parameter.empty:
+                rd, md = rp[name].default, mp[name].default
+                if isinstance(rd, (bool, int, float, str, type(None))) and (type(rd) is not type(md) or rd != md):  # literal defaults must be the reference's
+                    problems.append(f"{label}: parameter {name} defaults to {rd!r} in the reference, {md!r} here")
 
     for mod in SURFACE_MODULES:
         ref, mine = importlib.import_module("alphazero." + mod), importlib.import_module("alphazero_amd." + mod)
@@ -244,3 +248,35 @@ def test_abstract_hooks_raise_like_the_reference(R):
         R.c4.Connect4Net(7, 6).rotate_neural_output(np.zeros(7), 1)
     # a positional call binds as in the reference: play_game(False, False, False, True) asks for the results
     assert list(inspect.signature(Arena.play_game).parameters)[:5] == ["self", "player2_starts", "display", "save_frames", "return_results"]
+
+
+def test_config_dataclasses_have_the_references_fields_and_defaults(R):
+    """base.py:60-92 and games/*.py: the JSON configs of the reference load unchanged only if every field exists here under the same
+    name with the same default, in the same order (positional construction)"""
+    import dataclasses
+    from alphazero_amd import base as mbase
+    from alphazero_amd.games import connect4 as mc4, othello as moth, tictactoe as mttt
+    import alphazero.base as rbase
+    pairs = [(rbase.Config, mbase.Config), (R.oth.OthelloConfig, moth.OthelloConfig), (R.c4.Connect4Config, mc4.Connect4Config),
+             (R.ttt.TicTacToeConfig, mttt.TicTacToeConfig)]
+    for ref, mine in pairs:
+        rf = [(f.name, f.default) for f in dataclasses.fields(ref)]
+        mf = [(f.name, f.default) for f in dataclasses.fields(mine)]
+        assert rf == mf, (ref.__name__, [x for x in rf if x not in mf], [x for x in mf if x not in rf])
+        assert dict(ref().to_dict()) == dict(mine().to_dict())
+
+
+def test_registers_have_the_references_keys(R):
+    """games/registers.py: the same games, the same per-game entries (class names) and the same augmentation strategies"""
+    import alphazero_amd.games.registers as mreg
+    rreg = R.registers
+    for name in ("GAMES_SET", "CONFIGS_REGISTER", "BOARDS_REGISTER", "NETWORKS_REGISTER", "DATA_AUGMENT_STRATEGIES"):
+        a, b = getattr(rreg, name), getattr(mreg, name)
+        assert set(a) == set(b), name
+        if name.endswith("_REGISTER"):
+            assert {k: v.__name__ for k, v in a.items()} == {k: v.__name__ for k, v in b.items()}, name
+    for game, strat in rreg.DATA_AUGMENT_STRATEGIES.items():
+        mine = mreg.DATA_AUGMENT_STRATEGIES[game]
+        flat = lambda d: {k: [t.value for t in (v if isinstance(v, list) else [v])] for k, v in d.items()}
+        assert flat(strat) == flat(mine), game
+    assert {k: v.value for k, v in rreg.MOVE_FORMATS_REGISTER.items()} == {k: v.value for k, v in mreg.MOVE_FORMATS_REGISTER.items()}
